@@ -1,0 +1,426 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the reference.
+
+Runs ONLY in the build container (needs /root/reference; the GPU box has no
+reference).  The reference's modules are imported unmodified from
+/root/reference/src with two stand-in packages on sys.path (tools/refshim:
+gensim, qpsolvers -- absent from this image).  Nothing
+of the reference is copied: the outputs are data (inputs + expected outputs).
+
+    python tools/make_golden.py [case ...]
+
+Every .npz records numpy/scipy/sklearn versions: the reference delegates its
+solver to scipy (stm.py:960), so goldens are "the reference as imported here".
+"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, os.path.join(REF, "src"))
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+import sklearn  # noqa: E402
+
+import modules.stm as ref_stm  # noqa: E402
+from modules.generate_docs import CorpusCreation  # noqa: E402
+from modules.stm import STM  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+VERS = dict(numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__)
+
+
+class RecSTM(STM):
+    """Reference STM with per-document recording wrapped around its own methods."""
+
+    def _rec_reset(self):
+        self.rec = dict(status=[], nit=[], nfev=[], njev=[], fun=[], pd_path=[], bound=[],
+                        hess=[], chol=[], nu=[])
+        self._keep_mats = getattr(self, "_keep_mats", False)
+
+    def optimize_eta(self, eta, mu, word_count, beta_doc):
+        res = super().optimize_eta(eta, mu, word_count, beta_doc)
+        r = self.rec
+        r["status"].append(res.status); r["nit"].append(res.nit)
+        r["nfev"].append(res.nfev); r["njev"].append(res.njev); r["fun"].append(res.fun)
+        return res
+
+    def make_pd(self, M):
+        self._make_pd_calls = getattr(self, "_make_pd_calls", 0) + 1
+        return super().make_pd(M)
+
+    def decompose_hessian(self, hess, approx):
+        L = super().decompose_hessian(hess, approx)
+        if self._keep_mats:
+            self.rec["chol"].append(L.copy())
+        return L
+
+    def optimize_nu(self, L):
+        nu = super().optimize_nu(L)
+        if self._keep_mats:
+            self.rec["nu"].append(nu.copy())
+        return nu
+
+    def lower_bound(self, L, mu, word_count, beta_doc_kv, eta):
+        b = super().lower_bound(L, mu, word_count, beta_doc_kv, eta)
+        self.rec["bound"].append(float(b))
+        return b
+
+
+# The +1e-5 branch is detected by patching np.fill_diagonal only while inside hessian():
+_orig_fill = np.fill_diagonal
+
+
+def _install_plus_detector(model):
+    model._last_plus = False
+
+    def hessian(eta, word_count, beta_doc_kv):
+        model._last_plus = False
+        calls = {"n": 0}
+
+        def fill(a, val, wrap=False):
+            calls["n"] += 1
+            return _orig_fill(a, val, wrap)
+
+        np.fill_diagonal = fill
+        try:
+            # fill_diagonal is called once for the Hessian diagonal, once per make_pd,
+            # and once more for the +1e-5 branch.
+            STM_hess = STM.hessian
+            model._make_pd_calls = 0
+            f = STM_hess(model, eta, word_count, beta_doc_kv)
+        finally:
+            np.fill_diagonal = _orig_fill
+        path = 0
+        if model._make_pd_calls:
+            path = 2 if calls["n"] >= 3 else 1
+        model.rec["pd_path"].append(path)
+        if model._keep_mats:
+            model.rec["hess"].append(f.copy())
+        return f
+
+    model.hessian = hessian
+
+
+def docs_to_csr(docs):
+    indptr = np.zeros(len(docs) + 1, dtype=np.int64)
+    idx, cnt = [], []
+    for i, d in enumerate(docs):
+        for w, c in d:
+            idx.append(int(w)); cnt.append(float(c))
+        indptr[i + 1] = len(idx)
+    return indptr, np.asarray(idx, dtype=np.int32), np.asarray(cnt, dtype=np.float64)
+
+
+def run_em(model, n_iter, keep_beta_ss="full", sample_cols=None):
+    """Run n_iter EM iterations on a RecSTM, recording state around every step."""
+    out = {}
+    for it in range(n_iter):
+        model._rec_reset()
+        eta0 = model.eta.copy()
+        mu0 = model.mu.copy()
+        sigma0 = model.sigma.copy()
+        t = time.time()
+        beta_ss, sigma_ss = model.E_step()
+        te = time.time() - t
+        p = f"it{it}_"
+        out[p + "eta_in"] = eta0
+        out[p + "mu_in"] = mu0
+        out[p + "sigma_in"] = sigma0
+        out[p + "siginv"] = np.asarray(model.siginv)
+        out[p + "sigmaentropy"] = np.float64(model.sigmaentropy)
+        out[p + "eta"] = model.eta.copy()
+        out[p + "theta"] = model.theta.copy()
+        out[p + "bound"] = np.float64(model.bound)
+        out[p + "bound_doc"] = np.asarray(model.rec["bound"])
+        for k in ("status", "nit", "nfev", "njev", "pd_path"):
+            out[p + k] = np.asarray(model.rec[k], dtype=np.int32)
+        out[p + "fun"] = np.asarray(model.rec["fun"], dtype=np.float64)
+        out[p + "sigma_ss"] = sigma_ss.copy()
+        if keep_beta_ss == "full":
+            out[p + "beta_ss"] = beta_ss.copy()
+        else:
+            out[p + "beta_ss_rowsum"] = beta_ss.sum(axis=-1)
+            out[p + "beta_ss_colsum"] = beta_ss.sum(axis=-2)
+            out[p + "beta_ss_cols"] = beta_ss[..., sample_cols].copy()
+        out[p + "phi_last"] = np.asarray(model.phi).copy()
+        out[p + "estep_seconds"] = np.float64(te)
+        if model._keep_mats:
+            out[p + "hess"] = np.asarray(model.rec["hess"])
+            out[p + "chol"] = np.asarray(model.rec["chol"])
+            out[p + "nu"] = np.asarray(model.rec["nu"])
+        model.M_step(beta_ss, sigma_ss)
+        out[p + "mu_out"] = model.mu.copy()
+        out[p + "sigma_out"] = model.sigma.copy()
+        if keep_beta_ss == "full":
+            out[p + "beta_out"] = np.asarray(model.beta).copy()
+        else:
+            out[p + "beta_out_cols"] = np.asarray(model.beta)[..., sample_cols].copy()
+        if hasattr(model, "gamma"):
+            out[p + "gamma"] = np.asarray(model.gamma).copy()
+        print(f"    it{it}: bound={model.bound!r} estep={te:.1f}s "
+              f"status2={np.mean(np.asarray(model.rec['status']) == 2):.3f} "
+              f"nit_mean={np.mean(model.rec['nit']):.2f} pd_path={np.bincount(model.rec['pd_path'], minlength=3)}")
+    return out
+
+
+def make_model(docs, dictionary, K, X, model_type="STM", content=False, interactions=False,
+               beta_index=None, A=None, max_em_iter=3, keep_mats=False):
+    m = RecSTM(documents=docs, dictionary=dictionary, content=content, K=K, X=X,
+               kappa_interactions=interactions, max_em_iter=max_em_iter, sigma_prior=0,
+               convergence_threshold=1e-5, init_type="random", model_type=model_type,
+               beta_index=beta_index, A=A)
+    m._keep_mats = keep_mats
+    _install_plus_detector(m)
+    return m
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    arrs["versions"] = np.asarray(json.dumps(VERS))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# --------------------------------------------------------------------------
+def case_toy_ctm():
+    """tests/test_integration.py:14-68 of the reference (K=3, CTM, 2 EM iterations)."""
+    np.random.seed(42)
+    K, V, N, n_words, level = 3, 200, 50, 50, 1
+    gamma = np.random.multivariate_normal(np.random.standard_normal(level),
+                                          np.diag(np.full(level, 0.001)), K - 1)
+    corpus = CorpusCreation(n_topics=K, n_docs=N, n_words=n_words, V=V, level=level, dgp="STM",
+                            gamma=gamma)
+    corpus.generate_documents(remove_terms=True)
+    corpus.split_corpus(proportion=0.8)
+    docs = corpus.train_docs
+    np.random.seed(42)
+    X = corpus.metadata[:len(docs)]
+    m = make_model(docs, corpus.dictionary, K, X, model_type="CTM", max_em_iter=2, keep_mats=True)
+    beta0 = m.beta.copy()
+    out = run_em(m, 2)
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("toy_ctm", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(X, dtype=np.float64),
+         K=np.int32(K), V=np.int32(len(corpus.dictionary)), beta0=beta0,
+         final_bound=np.float64(m.last_bounds[-1]), **out)
+
+
+def _synthetic(K, V, n_docs, seed):
+    np.random.seed(seed)
+    c = CorpusCreation(n_topics=K, n_docs=n_docs, n_words=150, V=V, level=1, dgp="STM")
+    c.generate_documents(remove_terms=True)
+    return c
+
+
+def case_c1_k10():
+    """BASELINE config 0 shape: src/04 recipe, 1k docs x 150 words, V=2k, K=10, prevalence only."""
+    K = 10
+    c = _synthetic(K, 2000, 1000, 12345)
+    docs = c.documents
+    m = make_model(docs, c.dictionary, K, c.metadata, max_em_iter=3)
+    beta0 = m.beta.copy()
+    out = run_em(m, 3)
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("c1_k10", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(c.metadata, dtype=np.float64),
+         K=np.int32(K), V=np.int32(len(c.dictionary)), beta0=beta0, **out)
+
+
+def case_k50_v10k():
+    """BASELINE config 1 shape at 300 documents: K=50, V=10k, 150 words/doc."""
+    K = 50
+    c = _synthetic(K, 10000, 300, 2024)
+    docs = c.documents
+    m = make_model(docs, c.dictionary, K, c.metadata, max_em_iter=2)
+    V = len(c.dictionary)
+    cols = np.linspace(0, V - 1, 64).astype(np.int64)
+    beta0_cols = m.beta[:, cols].copy()
+    out = run_em(m, 2, keep_beta_ss="summary", sample_cols=cols)
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("k50_v10k", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(c.metadata, dtype=np.float64),
+         K=np.int32(K), V=np.int32(V), sample_cols=cols, beta0_cols=beta0_cols, **out)
+
+
+def case_wiki_k50():
+    """src/03_fit_reference_model.py:40-74 config on the shipped wiki BoW corpus; EM its 0-1.
+    ELBO[0] is pinned by the shipped src/artifacts/reference_model/50/lower_bound.pickle."""
+    import pickle
+
+    import pandas as pd
+    from scipy.io import mmread
+    art = os.path.join(REF, "src", "artifacts")
+    M = mmread(os.path.join(art, "wiki_data", "BoW_corpus.mm")).tocsr()
+    M.sort_indices()
+    docs = []
+    for i in range(M.shape[0]):
+        sl = slice(M.indptr[i], M.indptr[i + 1])
+        docs.append([(int(w), float(v)) for w, v in zip(M.indices[sl], M.data[sl])])
+    data = pd.read_csv(os.path.join(art, "wiki_data", "corpus_preproc.csv"))
+    xmat = np.array(data.loc[:, ["statistics"]])
+    dictionary = {i: str(i) for i in range(M.shape[1])}
+    shipped = pickle.load(open(os.path.join(art, "reference_model", "50", "lower_bound.pickle"), "rb"))
+    K = 50
+    np.random.seed(12345)
+    m = make_model(docs, dictionary, K, xmat, max_em_iter=25)
+    V = M.shape[1]
+    cols = np.linspace(0, V - 1, 64).astype(np.int64)
+    out = run_em(m, 2, keep_beta_ss="summary", sample_cols=cols)
+    print("    shipped ELBO[0:2] =", shipped[0], shipped[1])
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("wiki_k50", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(xmat, dtype=np.float64),
+         K=np.int32(K), V=np.int32(V), sample_cols=cols,
+         shipped_lower_bound=np.asarray(shipped, dtype=np.float64), **out)
+
+
+def case_content_a2():
+    """BASELINE config 4 shape, toy size: content covariate with A=2 levels, 3-D beta."""
+    K, A = 5, 2
+    c = _synthetic(K, 300, 120, 777)
+    docs = c.documents
+    rng = np.random.default_rng(5)
+    bidx = rng.integers(0, A, size=len(docs))
+    m = make_model(docs, c.dictionary, K, c.metadata, content=True, interactions=True,
+                   beta_index=bidx, A=A, max_em_iter=2)
+    beta0 = m.beta.copy()
+    out = run_em(m, 2)
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("content_a2", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(c.metadata, dtype=np.float64),
+         K=np.int32(K), V=np.int32(len(c.dictionary)), A=np.int32(A), aspect=bidx.astype(np.int32),
+         beta0=beta0, **out)
+
+
+def case_edge():
+    """Hand-made ragged corpus + non-trivial state (random mu/eta start, dense Sigma)."""
+    rng = np.random.default_rng(99)
+    K, V = 6, 300
+    docs = []
+    docs.append([(5, 1)])                                   # single word, count 1
+    docs.append([(17, 50)])                                 # single word, heavy count
+    docs.append([(int(w), 1) for w in range(0, 300)])       # every word once (Nd = V = 300)
+    docs.append([(int(w), int(rng.integers(1, 4))) for w in sorted(rng.choice(V, 200, replace=False))])
+    docs.append([(3, 1000), (4, 1)])                        # huge count
+    docs.append([(int(w), int(rng.integers(1, 30))) for w in sorted(rng.choice(V, 65, replace=False))])
+    docs.append([(int(w), 1) for w in sorted(rng.choice(V, 64, replace=False))])
+    docs.append([(int(w), 2) for w in sorted(rng.choice(V, 63, replace=False))])
+    for _ in range(40):
+        nd = int(rng.integers(2, 130))
+        docs.append([(int(w), int(rng.integers(1, 6))) for w in sorted(rng.choice(V, nd, replace=False))])
+    X = rng.integers(0, 2, size=(len(docs), 1))
+    dictionary = {i: str(i) for i in range(V)}
+    m = make_model(docs, dictionary, K, X, max_em_iter=2, keep_mats=True)
+    n = K - 1
+    m.mu = rng.normal(0, 0.5, size=(len(docs), n))
+    m.eta = rng.normal(0, 0.5, size=(len(docs), n))
+    Bm = rng.normal(size=(n, n))
+    m.sigma = Bm @ Bm.T + 0.5 * np.eye(n)
+    beta0 = m.beta.copy()
+    out = run_em(m, 2)
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("edge", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(X, dtype=np.float64),
+         K=np.int32(K), V=np.int32(V), beta0=beta0, **out)
+
+
+def case_functions():
+    """Per-function vectors: f/df at random points (closures of stm.py:920-958 captured by
+    intercepting the scipy call), make_pd / decompose_hessian / optimize_nu on crafted matrices."""
+    rng = np.random.default_rng(7)
+    K = 8
+    c = _synthetic(K, 400, 12, 31337)
+    docs = c.documents
+    m = make_model(docs, c.dictionary, K, c.metadata, max_em_iter=1)
+    n = K - 1
+    Bm = rng.normal(size=(n, n))
+    m.sigma = Bm @ Bm.T + np.eye(n)
+    sigobj = np.linalg.cholesky(m.sigma)
+    m.siginv = np.linalg.inv(sigobj).T * np.linalg.inv(sigobj)   # stm.py:501 (same expression)
+    m.sigmaentropy = np.sum(np.log(np.diag(sigobj)))
+    captured = {}
+
+    def fake_minimize(f, x0, args=(), jac=None, method=None):
+        captured["f"], captured["df"], captured["args"] = f, jac, args
+        raise StopIteration
+
+    real = ref_stm.optimize.minimize
+    fvals, gvals, etas, mus, bfgs_x, bfgs_status, bfgs_nit, bfgs_fun = [], [], [], [], [], [], [], []
+    # also a DENSE siginv variant (what a non-reference caller could hand in)
+    dense = np.linalg.inv(m.sigma)
+    fvals_d, gvals_d, bfgs_x_d, bfgs_status_d, bfgs_nit_d = [], [], [], [], []
+    for i, d in enumerate(docs):
+        arr = np.array(d)
+        idx, cnt = arr[:, 0], arr[:, 1]
+        bd = m.get_beta(idx, None)
+        mu = rng.normal(0, 0.3, n)
+        mus.append(mu)
+        pts = rng.normal(0, 1.0, size=(4, n))
+        pts[0] = 0.0
+        etas.append(pts)
+        for dense_flag in (False, True):
+            keep = m.siginv
+            if dense_flag:
+                m.siginv = dense
+            ref_stm.optimize.minimize = fake_minimize
+            try:
+                m.optimize_eta(pts[1], mu, cnt, bd)
+            except StopIteration:
+                pass
+            finally:
+                ref_stm.optimize.minimize = real
+            f, df, args = captured["f"], captured["df"], captured["args"]
+            fv = [float(f(p, *args)) for p in pts]
+            gv = [np.asarray(df(p, *args)) for p in pts]
+            res = STM.optimize_eta(m, pts[1].copy(), mu, cnt, bd)
+            if dense_flag:
+                fvals_d.append(fv); gvals_d.append(gv); bfgs_x_d.append(res.x)
+                bfgs_status_d.append(res.status); bfgs_nit_d.append(res.nit)
+            else:
+                fvals.append(fv); gvals.append(gv); bfgs_x.append(res.x)
+                bfgs_status.append(res.status); bfgs_nit.append(res.nit); bfgs_fun.append(res.fun)
+            m.siginv = keep
+    # crafted matrices for make_pd / decompose / nu
+    mats, names = [], []
+    Bm = rng.normal(size=(n, n)); mats.append(Bm @ Bm.T + n * np.eye(n)); names.append("pd")
+    S = rng.normal(size=(n, n)); S = S + S.T; mats.append(S); names.append("indefinite")
+    Z = np.array([[1.0, -1.0], [-1.0, 1.0]]); Zp = np.zeros((n, n)); Zp[:2, :2] = Z
+    Zp[2:, 2:] = np.eye(n - 2); mats.append(Zp); names.append("singular_dd")
+    S2 = -np.abs(S); np.fill_diagonal(S2, -3.0); mats.append(S2); names.append("negdiag")
+    mk, Ls, nus, mk_in = [], [], [], []
+    for Mx in mats:
+        a = Mx.copy()
+        mk_in.append(Mx.copy())
+        mk.append(STM.make_pd(m, a.copy()))
+        h = Mx.copy()
+        Lx = STM.decompose_hessian(m, h, approx=None)
+        Ls.append(Lx); nus.append(STM.optimize_nu(m, Lx))
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("functions", indptr=indptr, indices=idx, counts=cnt, K=np.int32(K),
+         V=np.int32(len(c.dictionary)), beta0=m.beta.copy(), siginv=np.asarray(m.siginv),
+         siginv_dense=dense, mus=np.asarray(mus), etas=np.asarray(etas),
+         fvals=np.asarray(fvals), gvals=np.asarray(gvals), bfgs_x=np.asarray(bfgs_x),
+         bfgs_status=np.asarray(bfgs_status), bfgs_nit=np.asarray(bfgs_nit), bfgs_fun=np.asarray(bfgs_fun),
+         fvals_dense=np.asarray(fvals_d), gvals_dense=np.asarray(gvals_d),
+         bfgs_x_dense=np.asarray(bfgs_x_d), bfgs_status_dense=np.asarray(bfgs_status_d),
+         bfgs_nit_dense=np.asarray(bfgs_nit_d),
+         mats=np.asarray(mk_in), mat_names=np.asarray(names), make_pd=np.asarray(mk),
+         chol=np.asarray(Ls), nu=np.asarray(nus))
+
+
+CASES = dict(toy_ctm=case_toy_ctm, functions=case_functions, edge=case_edge,
+             content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
+             wiki_k50=case_wiki_k50)
+
+if __name__ == "__main__":
+    import logging
+    import warnings
+    warnings.filterwarnings("ignore")
+    logging.disable(logging.CRITICAL)
+    which = sys.argv[1:] or list(CASES)
+    for name in which:
+        print(f"[{name}]")
+        t = time.time()
+        CASES[name]()
+        print(f"  done in {time.time() - t:.1f}s")
