@@ -1,0 +1,144 @@
+/*
+ * stm_estep.h -- C-ABI of the MI355X-native STM E-step library (libstm_hip.so).
+ *
+ * The reference (mkrcke/strutopy) is pure Python and has NO FFI / plugin
+ * interface: the boundary this library sits behind is the method surface of
+ * its `STM` class (reference src/modules/stm.py:310).  Each entry point below
+ * names the reference code it replaces; strutopy_amd/stm.py binds them with
+ * ctypes and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; device memory is owned by
+ *    the handle, host buffers by the caller (C-contiguous, fp64 unless noted);
+ *    the library never keeps a host pointer past the call.
+ *  - every function returns 0 on success, a STM_ERR_* code otherwise;
+ *    stm_last_error() returns a thread-local message for the last failure.
+ *  - one handle = one GPU = one HIP stream; handles share no mutable state,
+ *    so one process per GPU (or one thread per handle) is safe.
+ *  - matrices use the reference's layouts: beta [A][K][V], eta/mu [N][K-1],
+ *    theta [N][K], sigma/siginv/sigma_ss [(K-1)][(K-1)].
+ */
+#ifndef STM_ESTEP_H
+#define STM_ESTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STM_OK 0
+#define STM_ERR_INVALID 1     /* bad argument / call order */
+#define STM_ERR_BETA 2        /* "Some entries of beta are negative or nan." (stm.py:534) */
+#define STM_ERR_LINALG 3      /* Cholesky failed after every fallback (stm.py:1040-1048) */
+#define STM_ERR_HIP 4         /* HIP runtime error */
+#define STM_ERR_NO_DEVICE 5   /* no usable GPU */
+#define STM_ERR_COMM 6        /* RCCL error */
+#define STM_ERR_PHI 7         /* "Some values of phi are zero or nan." (stm.py:1117) */
+
+typedef struct stm_handle stm_handle;
+
+/* ---- lifetime --------------------------------------------------------- */
+int stm_create(stm_handle **out, int device_ordinal);
+void stm_destroy(stm_handle *h);
+const char *stm_last_error(void);
+/* "gfx950 ...": name + CU count of the device behind the handle */
+int stm_device_info(stm_handle *h, char *name_out, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- corpus and model state (replaces STM.__init__ state, stm.py:366-399) */
+/* documents as CSR (the packed form of the reference's list-of-(id,count) BoW,
+ * stm.py:522-533): indptr[N+1], indices[nnz] (unique within a document,
+ * 0 <= id < V), counts[nnz] (integers stored as fp64), aspect[N] (level of the
+ * content covariate per document, stm.py:527-528; NULL when A == 1). */
+int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr,
+                   const int32_t *indices, const double *counts, const int32_t *aspect, int32_t A);
+/* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467 */
+int stm_set_topics(stm_handle *h, int32_t K);
+int stm_put_beta(stm_handle *h, const double *beta /* [A][K][V] */);
+int stm_put_eta(stm_handle *h, const double *eta /* [N][K-1] */);
+int stm_put_mu(stm_handle *h, const double *mu /* [N][K-1] */);
+int stm_get_beta(stm_handle *h, double *beta);
+int stm_get_eta(stm_handle *h, double *eta);
+int stm_get_mu(stm_handle *h, double *mu);
+int stm_get_theta(stm_handle *h, double *theta /* [N][K] */);
+
+/* ---- the hot path: STM.E_step (stm.py:489-597) ------------------------ */
+/* siginv / sigmaentropy are the reference preamble's values (stm.py:499-501),
+ * computed by the caller with the reference's own expression.  Runs the
+ * per-document BFGS (stm.py:917-962 + scipy BFGS), theta (547-549), Hessian
+ * (986-1026), Cholesky (1031-1050), bound (1068-1101), nu (1052-1066), phi
+ * (1103-1118) and accumulates sigma_ss / beta_ss (582-588) on the GPU.
+ * eta is updated in place on the device; *bound_total = sum of bounds (592). */
+int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *bound_total);
+int stm_get_sigma_ss(stm_handle *h, double *sigma_ss /* [(K-1)^2] */);
+int stm_get_beta_ss(stm_handle *h, double *beta_ss /* [A][K][V] */);
+int stm_get_bound_docs(stm_handle *h, double *bound /* [N] */);
+/* per-document solver diagnostics of the last E-step (any pointer may be NULL):
+ * scipy OptimizeResult.status / .nit, evaluation counts, PD-fix path
+ * (0 none, 1 make_pd, 2 make_pd + 1e-5; stm.py:1017-1021) */
+int stm_get_diagnostics(stm_handle *h, int32_t *status, int32_t *nit, int32_t *nfev, int32_t *njev,
+                        int32_t *pd_path);
+/* phi (K x Nd) of one document as left in self.phi by stm.py:1116 */
+int stm_get_phi(stm_handle *h, int64_t doc, double *phi);
+
+/* One-shot form over host buffers (upload, E-step, download): what a
+ * reference-side `STM.E_step` stub would call.  Same field meaning as above. */
+typedef struct stm_estep_args {
+    int64_t N;
+    int32_t K, V, A;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const double *counts;
+    const int32_t *aspect;  /* nullable */
+    const double *beta;     /* [A][K][V] */
+    const double *mu;       /* [N][K-1] */
+    double *eta;            /* [N][K-1] in/out */
+    const double *siginv;   /* [(K-1)^2] */
+    double sigmaentropy;
+    double *theta;          /* [N][K] out */
+    double *bound;          /* [N] out, nullable */
+    double *sigma_ss;       /* out */
+    double *beta_ss;        /* out */
+    double *bound_total;    /* out */
+    int32_t *status, *nit, *nfev, *njev, *pd_path; /* out, nullable */
+} stm_estep_args;
+int stm_estep_host(const stm_estep_args *args, int device_ordinal);
+
+/* ---- M-step on the device (stm.py:622-747, next-row f-1) -------------- */
+/* prevalence covariates X [N][p] as used by update_mu (stm.py:661-671, already
+ * one-hot encoded by the host when the reference would encode them) */
+int stm_put_covariates(stm_handle *h, const double *X, int32_t p);
+/* local (this shard's) regression moments for update_mu (stm.py:678-706):
+ * out = [ n_docs | sum_x (p) | sum_eta (K-1) | XtX (p*p) | Xt_eta (p*(K-1)) ] */
+int stm_mstep_moments(stm_handle *h, double *out, int64_t out_len);
+/* mu_d = x_d @ gamma^T (stm.py:706; gamma [(K-1)][p]) or, when gamma == NULL,
+ * mu_d = mean_eta (CTM branch, stm.py:651; mean_eta [(K-1)]) */
+int stm_mstep_set_mu(stm_handle *h, const double *gamma, const double *mean_eta);
+/* covariance = (eta - mu)^T (eta - mu) of this shard (stm.py:723) */
+int stm_mstep_covariance(stm_handle *h, double *cov /* [(K-1)^2] */);
+/* beta = beta_ss / rowsum over words (stm.py:741-745; for 3-D beta_ss the
+ * reference's axis=1 sum runs over topics -- reproduced) from the (reduced)
+ * beta_ss held on the device */
+int stm_mstep_update_beta(stm_handle *h);
+
+/* ---- multi-GPU: one RCCL all-reduce of the sufficient statistics ------- */
+/* rank 0 calls stm_comm_unique_id and ships the 128 bytes to the other ranks
+ * (any side channel); then every rank calls stm_comm_init. */
+int stm_comm_unique_id(void *out128);
+int stm_comm_init(stm_handle *h, const void *uid128, int rank, int nranks);
+/* sum over ranks, in place on the device, of the packed buffer
+ * [ bound | sigma_ss | moments (extra_len doubles, host in/out) | beta_ss ] */
+int stm_allreduce_suffstats(stm_handle *h, double *bound_total, double *extra, int64_t extra_len);
+/* sum over ranks of a small host vector through the device (covariance) */
+int stm_allreduce_small(stm_handle *h, double *buf, int64_t len);
+
+/* ---- timing / profiling ---------------------------------------------- */
+/* HIP-event time (ms) of the kernels of the last stm_estep on the handle's
+ * stream: [0] solver kernel, [1] post kernel, [2] whole E-step */
+int stm_last_kernel_ms(stm_handle *h, float *ms3);
+int stm_synchronize(stm_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

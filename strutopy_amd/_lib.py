@@ -1,0 +1,128 @@
+"""ctypes binding of the C-ABI in include/stm_estep.h (libstm_hip.so).
+
+Host code stays Python + NumPy; this module is the only place that touches the
+shared library.  There is NO CPU fallback: if the HIP library is missing or no
+GPU is usable, loading / creating a handle raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstm_hip.so")
+
+STM_OK = 0
+STM_ERR_INVALID, STM_ERR_BETA, STM_ERR_LINALG, STM_ERR_HIP = 1, 2, 3, 4
+STM_ERR_NO_DEVICE, STM_ERR_COMM, STM_ERR_PHI = 5, 6, 7
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_h = C.c_void_p
+
+
+class EstepArgs(C.Structure):
+    """struct stm_estep_args (include/stm_estep.h)."""
+    _fields_ = [
+        ("N", C.c_int64), ("K", C.c_int32), ("V", C.c_int32), ("A", C.c_int32),
+        ("indptr", _lp), ("indices", _ip), ("counts", _dp), ("aspect", _ip),
+        ("beta", _dp), ("mu", _dp), ("eta", _dp), ("siginv", _dp), ("sigmaentropy", C.c_double),
+        ("theta", _dp), ("bound", _dp), ("sigma_ss", _dp), ("beta_ss", _dp), ("bound_total", _dp),
+        ("status", _ip), ("nit", _ip), ("nfev", _ip), ("njev", _ip), ("pd_path", _ip),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/stm_estep.h declares
+SIGNATURES = {
+    "stm_create": (C.c_int, [C.POINTER(_h), C.c_int]),
+    "stm_destroy": (None, [_h]),
+    "stm_last_error": (C.c_char_p, []),
+    "stm_device_info": (C.c_int, [_h, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "stm_set_corpus": (C.c_int, [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _ip, C.c_int32]),
+    "stm_set_topics": (C.c_int, [_h, C.c_int32]),
+    "stm_put_beta": (C.c_int, [_h, _dp]),
+    "stm_put_eta": (C.c_int, [_h, _dp]),
+    "stm_put_mu": (C.c_int, [_h, _dp]),
+    "stm_get_beta": (C.c_int, [_h, _dp]),
+    "stm_get_eta": (C.c_int, [_h, _dp]),
+    "stm_get_mu": (C.c_int, [_h, _dp]),
+    "stm_get_theta": (C.c_int, [_h, _dp]),
+    "stm_estep": (C.c_int, [_h, _dp, C.c_double, _dp]),
+    "stm_get_sigma_ss": (C.c_int, [_h, _dp]),
+    "stm_get_beta_ss": (C.c_int, [_h, _dp]),
+    "stm_get_bound_docs": (C.c_int, [_h, _dp]),
+    "stm_get_diagnostics": (C.c_int, [_h, _ip, _ip, _ip, _ip, _ip]),
+    "stm_get_phi": (C.c_int, [_h, C.c_int64, _dp]),
+    "stm_estep_host": (C.c_int, [C.POINTER(EstepArgs), C.c_int]),
+    "stm_put_covariates": (C.c_int, [_h, _dp, C.c_int32]),
+    "stm_mstep_moments": (C.c_int, [_h, _dp, C.c_int64]),
+    "stm_mstep_set_mu": (C.c_int, [_h, _dp, _dp]),
+    "stm_mstep_covariance": (C.c_int, [_h, _dp]),
+    "stm_mstep_update_beta": (C.c_int, [_h]),
+    "stm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "stm_comm_init": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
+    "stm_allreduce_suffstats": (C.c_int, [_h, _dp, _dp, C.c_int64]),
+    "stm_allreduce_small": (C.c_int, [_h, _dp, C.c_int64]),
+    "stm_last_kernel_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
+    "stm_synchronize": (C.c_int, [_h]),
+}
+# not part of the public header: debug dumps used by the parity tests
+_DEBUG_SIGNATURES = {
+    "stm_debug_get_mats": (C.c_int, [_h, _dp, _dp, _dp]),
+}
+
+_LIB = None
+
+
+class StmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libstm_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libstm_hip.so (built by __graft_entry__.build()); raise if it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  strutopy_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in {**SIGNATURES, **_DEBUG_SIGNATURES}.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    """Map C-ABI error codes onto the exceptions the reference raises for the same condition."""
+    if rc == STM_OK:
+        return
+    msg = lib().stm_last_error().decode(errors="replace")
+    if rc in (STM_ERR_BETA, STM_ERR_PHI):
+        raise AssertionError(msg)                 # stm.py:534 / stm.py:1117 are `assert`s
+    if rc == STM_ERR_LINALG:
+        raise np.linalg.LinAlgError(msg)          # np.linalg.cholesky failure, stm.py:1040
+    if rc == STM_ERR_INVALID:
+        raise ValueError(msg)
+    raise StmError(rc, msg)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def lptr(a):
+    return a.ctypes.data_as(_lp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,477 @@
+// stm_api.hip -- C-ABI (include/stm_estep.h) over the gfx950 E-step kernels.
+// Host side: device buffers, the single HIP stream, launches, HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/stm_estep.h"
+#include "stm_mstep.h"
+#include "stm_post.h"
+#include "stm_solver.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+// doubles reserved in the packed all-reduce buffer for the M-step moments
+constexpr size_t STM_EXTRA_MAX = 4096;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(STM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+template <class T>
+int dalloc(T **p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return STM_OK;
+}
+template <class T>
+void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// [A][R][C] -> [A][C][R]
+__global__ void transpose_kernel(const double *in, double *out, int R, int C) {
+    __shared__ double tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * C;
+    int c = blockIdx.x * 32 + threadIdx.x, r = blockIdx.y * 32 + threadIdx.y;
+    for (int dy = 0; dy < 32; dy += 8)
+        if (r + dy < R && c < C) tile[threadIdx.y + dy][threadIdx.x] = in[base + (size_t)(r + dy) * C + c];
+    __syncthreads();
+    int oc = blockIdx.y * 32 + threadIdx.x, orow = blockIdx.x * 32 + threadIdx.y;
+    for (int dy = 0; dy < 32; dy += 8)
+        if (orow + dy < C && oc < R) out[base + (size_t)(orow + dy) * R + oc] = tile[threadIdx.x][threadIdx.y + dy];
+}
+
+}  // namespace
+
+struct stm_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cu = 0;
+    std::string name;
+    size_t hbm = 0;
+    // corpus
+    int64_t N = 0, nnz = 0;
+    int V = 0, A = 1, maxNd = 0, NdPad = 64;
+    std::vector<int64_t> h_indptr;
+    int64_t *d_indptr = nullptr;
+    int32_t *d_indices = nullptr, *d_aspect = nullptr, *d_order = nullptr;
+    double *d_counts = nullptr;
+    // model
+    int K = 0, n = 0;
+    double *d_betaT = nullptr, *d_tmpKV = nullptr;
+    double *d_beta_ssT = nullptr, *d_sigma_ss = nullptr, *d_scal = nullptr;  // views into d_pack
+    double *d_eta = nullptr, *d_mu = nullptr, *d_theta = nullptr, *d_bound = nullptr;
+    double *d_siginv = nullptr, *d_sigma_part = nullptr;
+    int32_t *d_status = nullptr, *d_nit = nullptr, *d_nfev = nullptr, *d_njev = nullptr, *d_pd = nullptr;
+    int *d_counters = nullptr;
+    int32_t *d_err = nullptr;
+    double *d_slab_beta = nullptr, *d_slab_H = nullptr;
+    int chunk = 0, nrep = 256;   // documents per launch, replicated nu accumulators
+    // optional dumps
+    double *d_phi = nullptr;
+    int64_t phi_doc = -1;
+    double *d_hess = nullptr, *d_chol = nullptr, *d_nu = nullptr;
+    // M-step
+    int p = 0;
+    double *d_X = nullptr, *d_mom = nullptr, *d_gamma = nullptr, *d_cov = nullptr;
+    // comm
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+    double *d_pack = nullptr;
+    size_t pack_len = 0;
+    // timing
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float ms[3] = {0, 0, 0};
+    bool beta_set = false;
+};
+
+static int use_device(stm_handle *h) {
+    HIP_TRY(hipSetDevice(h->device));
+    return STM_OK;
+}
+
+extern "C" {
+
+const char *stm_last_error(void) { return g_err.c_str(); }
+
+int stm_create(stm_handle **out, int device_ordinal) {
+    if (!out) return fail(STM_ERR_INVALID, "stm_create: out is NULL");
+    *out = nullptr;
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(STM_ERR_NO_DEVICE, "no HIP device available (the E-step has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= cnt) return fail(STM_ERR_INVALID, "bad device ordinal");
+    stm_handle *h = new stm_handle();
+    h->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipSetDevice failed"); }
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, device_ordinal) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipGetDeviceProperties failed"); }
+    h->cu = pr.multiProcessorCount;
+    h->name = std::string(pr.gcnArchName) + " " + pr.name;
+    h->hbm = pr.totalGlobalMem;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipStreamCreate failed"); }
+    for (auto &ev : h->ev)
+        if (hipEventCreate(&ev) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipEventCreate failed"); }
+    *out = h;
+    return STM_OK;
+}
+
+void stm_destroy(stm_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    stm_mstep_comm_destroy(h->comm);
+    dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
+    dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_eta); dfree(h->d_mu);
+    dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
+    dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
+    dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
+    dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu);
+    dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack);
+    for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int stm_device_info(stm_handle *h, char *name_out, int name_len, int *cu_count, int64_t *hbm_bytes) {
+    if (!h) return fail(STM_ERR_INVALID, "null handle");
+    if (name_out && name_len > 0) {
+        strncpy(name_out, h->name.c_str(), (size_t)name_len - 1);
+        name_out[name_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = h->cu;
+    if (hbm_bytes) *hbm_bytes = (int64_t)h->hbm;
+    return STM_OK;
+}
+
+int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, const int32_t *indices,
+                   const double *counts, const int32_t *aspect, int32_t A) {
+    if (!h || N < 0 || V < 1 || !indptr) return fail(STM_ERR_INVALID, "stm_set_corpus: bad arguments");
+    if (N >= (int64_t)1 << 31) return fail(STM_ERR_INVALID, "stm_set_corpus: N must be < 2^31 per GPU shard");
+    if (A < 1) A = 1;
+    if (A > 1 && !aspect) return fail(STM_ERR_INVALID, "stm_set_corpus: A > 1 needs aspect[]");
+    if (int rc = use_device(h)) return rc;
+    const int64_t nnz = indptr[N] - indptr[0];
+    if (indptr[0] != 0 || nnz < 0) return fail(STM_ERR_INVALID, "stm_set_corpus: indptr must start at 0 and be monotone");
+    if (nnz > 0 && (!indices || !counts)) return fail(STM_ERR_INVALID, "stm_set_corpus: indices/counts are NULL");
+    int maxNd = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t nd = indptr[i + 1] - indptr[i];
+        if (nd < 1) return fail(STM_ERR_INVALID, "stm_set_corpus: empty document (the reference indexes doc_array[:, 0], stm.py:523)");
+        maxNd = std::max<int64_t>(maxNd, nd);
+    }
+    for (int64_t q = 0; q < nnz; ++q)
+        if (indices[q] < 0 || indices[q] >= V) return fail(STM_ERR_INVALID, "stm_set_corpus: word id out of range");
+    if (aspect)
+        for (int64_t i = 0; i < N; ++i)
+            if (aspect[i] < 0 || aspect[i] >= A) return fail(STM_ERR_INVALID, "stm_set_corpus: aspect out of range");
+    h->N = N; h->V = V; h->A = A; h->nnz = nnz; h->maxNd = maxNd;
+    h->NdPad = std::max(64, (maxNd + 63) / 64 * 64);
+    h->h_indptr.assign(indptr, indptr + N + 1);
+    if (int rc = dalloc(&h->d_indptr, (size_t)N + 1)) return rc;
+    if (int rc = dalloc(&h->d_indices, (size_t)nnz)) return rc;
+    if (int rc = dalloc(&h->d_counts, (size_t)nnz)) return rc;
+    if (int rc = dalloc(&h->d_order, (size_t)N)) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_indptr, indptr, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz) {
+        HIP_TRY(hipMemcpyAsync(h->d_indices, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_counts, counts, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+    }
+    dfree(h->d_aspect);
+    if (aspect && A > 1) {
+        if (int rc = dalloc(&h->d_aspect, (size_t)N)) return rc;
+        HIP_TRY(hipMemcpyAsync(h->d_aspect, aspect, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    }
+    // longest documents first: the work queue then ends on short ones (smaller tail)
+    std::vector<int32_t> order((size_t)N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (indptr[a + 1] - indptr[a]) > (indptr[b + 1] - indptr[b]);
+    });
+    if (N) HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->K = 0;
+    return STM_OK;
+}
+
+int stm_set_topics(stm_handle *h, int32_t K) {
+    if (!h || h->V == 0) return fail(STM_ERR_INVALID, "stm_set_topics: set the corpus first");
+    if (K < 2) return fail(STM_ERR_INVALID, "stm_set_topics: K must be >= 2");
+    if (K > 64) return fail(STM_ERR_INVALID, "stm_set_topics: K > 64 is not supported by this build yet");
+    if (int rc = use_device(h)) return rc;
+    h->K = K; h->n = K - 1;
+    const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
+    if (int rc = dalloc(&h->d_betaT, KV)) return rc;
+    // one packed buffer [ scalars(8) | sigma_ss | extra | beta_ss ] so a single all-reduce covers it
+    h->pack_len = 8 + n * n + STM_EXTRA_MAX + KV;
+    if (int rc = dalloc(&h->d_pack, h->pack_len)) return rc;
+    h->d_scal = h->d_pack;
+    h->d_sigma_ss = h->d_pack + 8;
+    h->d_beta_ssT = h->d_pack + 8 + n * n + STM_EXTRA_MAX;
+    if (int rc = dalloc(&h->d_tmpKV, KV)) return rc;
+    if (int rc = dalloc(&h->d_eta, N * n)) return rc;
+    if (int rc = dalloc(&h->d_mu, N * n)) return rc;
+    if (int rc = dalloc(&h->d_theta, N * K)) return rc;
+    if (int rc = dalloc(&h->d_bound, N)) return rc;
+    if (int rc = dalloc(&h->d_siginv, n * n)) return rc;
+    if (int rc = dalloc(&h->d_status, N)) return rc;
+    if (int rc = dalloc(&h->d_nit, N)) return rc;
+    if (int rc = dalloc(&h->d_nfev, N)) return rc;
+    if (int rc = dalloc(&h->d_njev, N)) return rc;
+    if (int rc = dalloc(&h->d_pd, N)) return rc;
+    if (int rc = dalloc(&h->d_counters, 8)) return rc;
+    if (int rc = dalloc(&h->d_err, 1)) return rc;
+    // one block (one wave) per document; documents are launched in chunks so the private
+    // slabs (beta_d columns + BFGS H) stay within a fixed HBM budget
+    const size_t slab_bytes = ((size_t)(K + 2) * h->NdPad + n * n) * sizeof(double);
+    const size_t budget = (size_t)env_int("STM_SLAB_BUDGET_MB", 24576) << 20;
+    h->chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(h->N, 1), (int64_t)(budget / slab_bytes)));
+    h->nrep = env_int("STM_SIGMA_REPLICAS", 256);
+    if (int rc = dalloc(&h->d_slab_beta, (size_t)h->chunk * (size_t)(K + 2) * h->NdPad)) return rc;
+    if (int rc = dalloc(&h->d_slab_H, (size_t)h->chunk * n * n)) return rc;
+    if (int rc = dalloc(&h->d_sigma_part, (size_t)h->nrep * n * n)) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_eta, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_mu, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_theta, 0, sizeof(double) * std::max<size_t>(N * K, 1), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->beta_set = false;
+    dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu);
+    if (env_int("STM_DEBUG_DUMP", 0)) {
+        if (int rc = dalloc(&h->d_hess, N * n * n)) return rc;
+        if (int rc = dalloc(&h->d_chol, N * n * n)) return rc;
+        if (int rc = dalloc(&h->d_nu, N * n * n)) return rc;
+    }
+    return STM_OK;
+}
+
+static int transpose3(stm_handle *h, const double *in, double *out, int R, int C) {
+    dim3 blk(32, 8), grd((C + 31) / 32, (R + 31) / 32, h->A);
+    hipLaunchKernelGGL(transpose_kernel, grd, blk, 0, h->stream, in, out, R, C);
+    HIP_TRY(hipGetLastError());
+    return STM_OK;
+}
+
+#define NEED_MODEL(h)                                                                   \
+    if (!(h) || (h)->K == 0) return fail(STM_ERR_INVALID, "call stm_set_corpus and stm_set_topics first"); \
+    if (int rc_ = use_device(h)) return rc_;
+
+int stm_put_beta(stm_handle *h, const double *beta) {
+    NEED_MODEL(h);
+    if (!beta) return fail(STM_ERR_INVALID, "beta is NULL");
+    const size_t KV = (size_t)h->A * h->K * h->V;
+    HIP_TRY(hipMemcpyAsync(h->d_tmpKV, beta, sizeof(double) * KV, hipMemcpyHostToDevice, h->stream));
+    if (int rc = transpose3(h, h->d_tmpKV, h->d_betaT, h->K, h->V)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->beta_set = true;
+    return STM_OK;
+}
+int stm_get_beta(stm_handle *h, double *beta) {
+    NEED_MODEL(h);
+    const size_t KV = (size_t)h->A * h->K * h->V;
+    if (int rc = transpose3(h, h->d_betaT, h->d_tmpKV, h->V, h->K)) return rc;
+    HIP_TRY(hipMemcpyAsync(beta, h->d_tmpKV, sizeof(double) * KV, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+int stm_get_beta_ss(stm_handle *h, double *beta_ss) {
+    NEED_MODEL(h);
+    const size_t KV = (size_t)h->A * h->K * h->V;
+    if (int rc = transpose3(h, h->d_beta_ssT, h->d_tmpKV, h->V, h->K)) return rc;
+    HIP_TRY(hipMemcpyAsync(beta_ss, h->d_tmpKV, sizeof(double) * KV, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+
+static int put_vec(stm_handle *h, double *dst, const double *src, size_t cnt) {
+    if (!src) return fail(STM_ERR_INVALID, "source pointer is NULL");
+    if (cnt) HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+static int get_vec(stm_handle *h, double *dst, const double *src, size_t cnt) {
+    if (!dst) return fail(STM_ERR_INVALID, "destination pointer is NULL");
+    if (cnt) HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+int stm_put_eta(stm_handle *h, const double *eta) { NEED_MODEL(h); return put_vec(h, h->d_eta, eta, (size_t)h->N * h->n); }
+int stm_put_mu(stm_handle *h, const double *mu) { NEED_MODEL(h); return put_vec(h, h->d_mu, mu, (size_t)h->N * h->n); }
+int stm_get_eta(stm_handle *h, double *eta) { NEED_MODEL(h); return get_vec(h, eta, h->d_eta, (size_t)h->N * h->n); }
+int stm_get_mu(stm_handle *h, double *mu) { NEED_MODEL(h); return get_vec(h, mu, h->d_mu, (size_t)h->N * h->n); }
+int stm_get_theta(stm_handle *h, double *theta) { NEED_MODEL(h); return get_vec(h, theta, h->d_theta, (size_t)h->N * h->K); }
+int stm_get_sigma_ss(stm_handle *h, double *s) { NEED_MODEL(h); return get_vec(h, s, h->d_sigma_ss, (size_t)h->n * h->n); }
+int stm_get_bound_docs(stm_handle *h, double *b) { NEED_MODEL(h); return get_vec(h, b, h->d_bound, (size_t)h->N); }
+
+int stm_get_diagnostics(stm_handle *h, int32_t *status, int32_t *nit, int32_t *nfev, int32_t *njev, int32_t *pd_path) {
+    NEED_MODEL(h);
+    const size_t bytes = sizeof(int32_t) * (size_t)h->N;
+    if (status) HIP_TRY(hipMemcpyAsync(status, h->d_status, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (nit) HIP_TRY(hipMemcpyAsync(nit, h->d_nit, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (nfev) HIP_TRY(hipMemcpyAsync(nfev, h->d_nfev, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (njev) HIP_TRY(hipMemcpyAsync(njev, h->d_njev, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (pd_path) HIP_TRY(hipMemcpyAsync(pd_path, h->d_pd, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+
+int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *bound_total) {
+    NEED_MODEL(h);
+    if (!h->beta_set) return fail(STM_ERR_INVALID, "stm_estep: beta has not been set");
+    if (!siginv) return fail(STM_ERR_INVALID, "stm_estep: siginv is NULL");
+    const int n = h->n, K = h->K;
+    int diag = 1;
+    for (int i = 0; i < n && diag; ++i)
+        for (int j = 0; j < n; ++j)
+            if (i != j && siginv[(size_t)i * n + j] != 0.0) { diag = 0; break; }
+    const size_t KV = (size_t)h->A * K * h->V;
+    HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)h->nrep * n * n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
+    // last document's phi is what the reference leaves in self.phi (stm.py:1116)
+    h->phi_doc = h->N - 1;
+    if (h->N > 0) {
+        const size_t nd = (size_t)(h->h_indptr[h->N] - h->h_indptr[h->N - 1]);
+        if (int rc = dalloc(&h->d_phi, (size_t)K * nd)) return rc;
+    }
+
+    stm::SolverParams sp{};
+    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.NdPad = h->NdPad;
+    sp.indptr = h->d_indptr; sp.indices = h->d_indices; sp.counts = h->d_counts; sp.aspect = h->d_aspect;
+    sp.betaT = h->d_betaT; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag;
+    sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
+    sp.order = h->d_order; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
+    sp.err_flag = h->d_err;
+    sp.debug_flags = env_int("STM_DEBUG_FLAGS", 0);
+
+    stm::PostParams pp{};
+    pp.N = h->N; pp.K = K; pp.n = n; pp.V = h->V;
+    pp.indptr = h->d_indptr; pp.indices = h->d_indices; pp.counts = h->d_counts; pp.aspect = h->d_aspect;
+    pp.betaT = h->d_betaT; pp.mu = h->d_mu; pp.eta = h->d_eta; pp.siginv = h->d_siginv; pp.siginv_diag = diag;
+    pp.sigmaentropy = sigmaentropy; pp.theta = h->d_theta; pp.bound = h->d_bound; pp.beta_ssT = h->d_beta_ssT;
+    pp.sigma_part = h->d_sigma_part; pp.nrep = h->nrep; pp.order = h->d_order;
+    pp.pd_path = h->d_pd; pp.err_flag = h->d_err;
+    pp.hess_out = h->d_hess; pp.chol_out = h->d_chol; pp.nu_out = h->d_nu;
+    pp.phi_doc = h->phi_doc; pp.phi_out = h->d_phi;
+
+    const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    if (dbg_stage & 1)
+        for (int64_t first = 0; first < h->N; first += h->chunk) {
+            sp.first = first;
+            const unsigned g = (unsigned)std::min<int64_t>(h->chunk, h->N - first);
+            hipLaunchKernelGGL(stm::solver_kernel<1>, dim3(g), dim3(64), 0, h->stream, sp);
+            HIP_TRY(hipGetLastError());
+        }
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    if (dbg_stage & 2)
+        for (int64_t first = 0; first < h->N; first += h->chunk) {
+            pp.first = first;
+            const unsigned g = (unsigned)std::min<int64_t>(h->chunk, h->N - first);
+            hipLaunchKernelGGL(stm::post_kernel, dim3(g), dim3(64), 0, h->stream, pp);
+            HIP_TRY(hipGetLastError());
+        }
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream,
+                       h->d_sigma_part, h->nrep, n * n, h->d_sigma_ss);
+    hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    double tot = 0.0;
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&tot, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&h->ms[1], h->ev[1], h->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&h->ms[2], h->ev[0], h->ev[3]));
+    if (bound_total) *bound_total = tot;
+    if (err == STM_ERR_BETA) return fail(STM_ERR_BETA, "Some entries of beta are negative or nan.");
+    if (err == STM_ERR_PHI) return fail(STM_ERR_PHI, "Some values of phi are zero or nan.");
+    if (err == STM_ERR_LINALG) return fail(STM_ERR_LINALG, "Cholesky decomposition of the Hessian failed after every fallback");
+    if (err) return fail(STM_ERR_INVALID, "device error flag " + std::to_string(err));
+    return STM_OK;
+}
+
+int stm_get_phi(stm_handle *h, int64_t doc, double *phi) {
+    NEED_MODEL(h);
+    if (doc != h->phi_doc || !h->d_phi) return fail(STM_ERR_INVALID, "stm_get_phi: only the last document's phi is kept (stm.py:1116)");
+    const size_t nd = (size_t)(h->h_indptr[doc + 1] - h->h_indptr[doc]);
+    return get_vec(h, phi, h->d_phi, (size_t)h->K * nd);
+}
+
+int stm_debug_get_mats(stm_handle *h, double *hess, double *chol, double *nu) {
+    NEED_MODEL(h);
+    if (!h->d_hess) return fail(STM_ERR_INVALID, "set STM_DEBUG_DUMP=1 before stm_set_topics");
+    const size_t cnt = (size_t)h->N * h->n * h->n;
+    if (hess) if (int rc = get_vec(h, hess, h->d_hess, cnt)) return rc;
+    if (chol) if (int rc = get_vec(h, chol, h->d_chol, cnt)) return rc;
+    if (nu) if (int rc = get_vec(h, nu, h->d_nu, cnt)) return rc;
+    return STM_OK;
+}
+
+int stm_last_kernel_ms(stm_handle *h, float *ms3) {
+    if (!h || !ms3) return fail(STM_ERR_INVALID, "null argument");
+    ms3[0] = h->ms[0]; ms3[1] = h->ms[1]; ms3[2] = h->ms[2];
+    return STM_OK;
+}
+int stm_synchronize(stm_handle *h) {
+    if (!h) return fail(STM_ERR_INVALID, "null handle");
+    if (int rc = use_device(h)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+
+int stm_estep_host(const stm_estep_args *a, int device_ordinal) {
+    if (!a) return fail(STM_ERR_INVALID, "null args");
+    stm_handle *h = nullptr;
+    int rc = stm_create(&h, device_ordinal);
+    if (rc) return rc;
+    auto done = [&](int code) { std::string keep = g_err; stm_destroy(h); g_err = keep; return code; };
+    if ((rc = stm_set_corpus(h, a->N, a->V, a->indptr, a->indices, a->counts, a->aspect, a->A))) return done(rc);
+    if ((rc = stm_set_topics(h, a->K))) return done(rc);
+    if ((rc = stm_put_beta(h, a->beta))) return done(rc);
+    if ((rc = stm_put_mu(h, a->mu))) return done(rc);
+    if ((rc = stm_put_eta(h, a->eta))) return done(rc);
+    double tot = 0.0;
+    if ((rc = stm_estep(h, a->siginv, a->sigmaentropy, &tot))) return done(rc);
+    if (a->bound_total) *a->bound_total = tot;
+    if ((rc = stm_get_eta(h, a->eta))) return done(rc);
+    if (a->theta && (rc = stm_get_theta(h, a->theta))) return done(rc);
+    if (a->bound && (rc = stm_get_bound_docs(h, a->bound))) return done(rc);
+    if (a->sigma_ss && (rc = stm_get_sigma_ss(h, a->sigma_ss))) return done(rc);
+    if (a->beta_ss && (rc = stm_get_beta_ss(h, a->beta_ss))) return done(rc);
+    if ((rc = stm_get_diagnostics(h, a->status, a->nit, a->nfev, a->njev, a->pd_path))) return done(rc);
+    return done(STM_OK);
+}
+
+}  // extern "C"
+
+#include "stm_mstep_api.inc"

@@ -1,0 +1,127 @@
+// stm_mstep.h -- device side of the M-step (reference src/modules/stm.py:622-747) that closes
+// one EM iteration without moving eta / mu / beta off the GPU, plus the RCCL binding.
+//
+//   moments_kernel     local regression moments for update_mu (stm.py:678-706)
+//   set_mu_kernel      mu = X @ gamma^T (stm.py:706) or the CTM column mean (stm.py:651)
+//   covariance_kernel  (eta - mu)^T (eta - mu) (stm.py:723)
+//   beta kernels       beta = beta_ss / rowsum (stm.py:741-745), word-major on the device
+//
+// All of these are thin HBM-bound streaming kernels over N x (K-1) or V x K doubles; the
+// tiny dense solves (p x p regression, (K-1)^2 Cholesky of Sigma) stay on the host, in the
+// Python mirror of the reference's M-step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stm {
+
+// per-block partials of [ N | sum_x (p) | sum_eta (n) | XtX (p*p) | Xt_eta (p*n) ]
+// one thread per output slot, docs strided over blocks; reduced by reduce_sigma_kernel
+__global__ __launch_bounds__(256) void moments_kernel(const double *X, const double *eta, int64_t N,
+                                                      int p, int n, double *part, int L) {
+    const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t d0 = (int64_t)blockIdx.x * chunk;
+    const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
+    for (int slot = threadIdx.x; slot < L; slot += blockDim.x) {
+        double t = 0.0;
+        int s = slot;
+        if (s == 0) {
+            t = (double)(d1 > d0 ? d1 - d0 : 0);
+        } else if ((s -= 1) < p) {
+            for (int64_t d = d0; d < d1; ++d) t += X[d * p + s];
+        } else if ((s -= p) < n) {
+            for (int64_t d = d0; d < d1; ++d) t += eta[d * n + s];
+        } else if ((s -= n) < p * p) {
+            const int a = s / p, b = s % p;
+            for (int64_t d = d0; d < d1; ++d) t += X[d * p + a] * X[d * p + b];
+        } else {
+            s -= p * p;
+            const int a = s / n, i = s % n;
+            for (int64_t d = d0; d < d1; ++d) t += X[d * p + a] * eta[d * n + i];
+        }
+        part[(size_t)blockIdx.x * L + slot] = t;
+    }
+}
+
+// mu[d][i] = sum_q X[d][q] * gamma[i][q]   (gamma [(n)][p]; stm.py:703-706: no intercept)
+// or mu[d][i] = mean_eta[i] when X == nullptr (CTM, stm.py:651)
+__global__ void set_mu_kernel(const double *X, const double *gamma, const double *mean_eta,
+                              int64_t N, int p, int n, double *mu) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N * n) return;
+    const int64_t d = q / n;
+    const int i = (int)(q % n);
+    if (!X) { mu[q] = mean_eta[i]; return; }
+    double t = 0.0;
+    for (int a = 0; a < p; ++a) t += X[d * p + a] * gamma[(size_t)i * p + a];
+    mu[q] = t;
+}
+
+// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j]; n <= 64.
+// 256 threads: thread (ty, tx) = (t / 64, t % 64) owns column j = tx of rows i = ty, ty+4, ...
+__global__ __launch_bounds__(256) void covariance_kernel(const double *eta, const double *mu, int64_t N,
+                                                         int n, double *part) {
+    constexpr int TD = 32;  // documents per LDS tile
+    __shared__ double diff[TD][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t d0 = (int64_t)blockIdx.x * chunk;
+    const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
+    for (int64_t base = d0; base < d1; base += TD) {
+        const int cnt = (int)((d1 - base) < TD ? (d1 - base) : TD);
+        for (int q = threadIdx.x; q < TD * 64; q += 256) {
+            const int dd = q >> 6, i = q & 63;
+            diff[dd][i] = (dd < cnt && i < n) ? eta[(base + dd) * n + i] - mu[(base + dd) * n + i] : 0.0;
+        }
+        __syncthreads();
+        for (int dd = 0; dd < cnt; ++dd) {
+            const double cj = diff[dd][tx];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fma(diff[dd][ty + 4 * r], cj, acc[r]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = ty + 4 * r;
+        if (i < n && tx < n) part[(size_t)blockIdx.x * n * n + (size_t)i * n + tx] = acc[r];
+    }
+}
+
+// column sums of the word-major beta_ss: part[block][k] = sum over the block's words of bssT[v][k]
+__global__ __launch_bounds__(256) void beta_rowsum_kernel(const double *bssT, int V, int K, double *part) {
+    const int k = threadIdx.x & 63, sub = threadIdx.x >> 6;  // 4 word lanes x 64 topics
+    __shared__ double sh[4][64];
+    const int chunk = (V + gridDim.x - 1) / gridDim.x;
+    const int v0 = blockIdx.x * chunk, v1 = v0 + chunk < V ? v0 + chunk : V;
+    double t = 0.0;
+    if (k < K)
+        for (int v = v0 + sub; v < v1; v += 4) t += bssT[(size_t)v * K + k];
+    sh[sub][k] = t;
+    __syncthreads();
+    if (sub == 0 && k < K) part[(size_t)blockIdx.x * K + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+}
+// betaT[v][k] = bssT[v][k] / rowsum[k] where rowsum != 0 else 0 (2-D beta, stm.py:741-745)
+__global__ void beta_normalise_kernel(const double *bssT, const double *rowsum, int64_t VK, int K, double *betaT) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= VK) return;
+    const double rs = rowsum[q % K];
+    betaT[q] = (rs != 0.0) ? bssT[q] / rs : 0.0;
+}
+// 3-D beta: the reference's np.sum(beta_ss, axis=1) runs over TOPICS, so every (level, word)
+// column is normalised by its own sum over k (stm.py:741 with a 3-D array)
+__global__ void beta_normalise_topics_kernel(const double *bssT, int64_t AV, int K, double *betaT) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= AV) return;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += bssT[r * K + k];
+    for (int k = 0; k < K; ++k) betaT[r * K + k] = (s != 0.0) ? bssT[r * K + k] / s : 0.0;
+}
+
+}  // namespace stm
+
+// RCCL binding (resolved lazily with dlopen so a single-GPU run never loads librccl)
+void stm_mstep_comm_destroy(void *comm);

@@ -1,0 +1,697 @@
+// stm_solver.h -- per-document variational optimisation of eta: one wavefront per document.
+//
+// Replaces, per document, reference src/modules/stm.py:532-546 (get_beta gather,
+// optimize_eta) -- i.e. scipy.optimize.minimize(f, x0=eta, jac=df, method="BFGS") with
+// the objective f (stm.py:920-944) and the gradient df (stm.py:946-958) exactly as the
+// reference defines them, and scipy's _minimize_bfgs / DCSRCH / Wolfe2 / zoom control
+// flow restated as ONE wave-uniform state machine with a single
+// evaluation site, so the K x Nd contraction is instantiated once.
+//
+// Data layout (HBM): beta is held word-major, betaT[A][V][K], so a word's K-vector is one
+// contiguous 8K-byte run; the document's columns are gathered once into a private,
+// L2-resident slab slab[k][NdPad] (v contiguous => every objective evaluation streams it
+// with fully coalesced 512-byte wave loads).  The BFGS inverse-Hessian estimate lives in
+// a second private slab (n x n, touched only nit times).  Lane i holds component i of
+// every length-(K-1) vector; all line-search scalars are wave-uniform.
+#pragma once
+#include "stm_wave.h"
+
+namespace stm {
+
+struct SolverParams {
+    int64_t N;
+    int K, n, V, NdPad;
+    const int64_t *indptr;
+    const int32_t *indices;
+    const double *counts;
+    const int32_t *aspect;  // nullable
+    const double *betaT;    // [A][V][K]
+    const double *mu;       // [N][n]
+    double *eta;            // [N][n] in/out
+    const double *siginv;   // [n][n]
+    int siginv_diag;        // 1: off-diagonals are exactly zero (what stm.py:501 produces)
+    double *slab_beta;      // [grid][(K+2)][NdPad]
+    double *slab_H;         // [grid][n][n]
+    int64_t first;          // this launch covers order[first .. first + gridDim.x)
+    const int32_t *order;   // optional processing order (nullable)
+    int32_t *status, *nit, *nfev, *njev;
+    int32_t *err_flag;
+    int debug_flags;        // bit0: skip the BFGS loop (bring-up aid)
+};
+
+enum : int {
+    S_INIT_DONE = 0, S_OUTER_TOP, S_W1_START, S_W1_ITER, S_W2_START, S_W2_FIRST, S_W2_TOP,
+    S_W2_GOT_G, S_W2_GOT_F, S_ZOOM_TOP, S_ZOOM_GOT_F, S_ZOOM_GOT_G, S_ZOOM_NEXT, S_ACCEPT,
+    S_ACCEPT2, S_FINISH
+};
+
+// scipy/optimize/_dcsrch.py:502-728 dcstep (wave-uniform scalars)
+__device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy,
+                                       double &dy, double &stp, double fp, double dp, bool &brackt,
+                                       double stpmin, double stpmax) {
+    const double sgnd = np_sign(dp) * np_sign(dx);
+    double stpf, stpc, stpq, theta, s, gamma, p, q, r;
+    if (fp > fx) {
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = py_max3(fabs(theta), fabs(dx), fabs(dp));
+        gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp < stx) gamma *= -1;
+        p = (gamma - dx) + theta;
+        q = ((gamma - dx) + gamma) + dp;
+        r = p / q;
+        stpc = stx + r * (stp - stx);
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+        if (fabs(stpc - stx) <= fabs(stpq - stx)) stpf = stpc;
+        else stpf = stpc + (stpq - stpc) / 2.0;
+        brackt = true;
+    } else if (sgnd < 0.0) {
+        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+        s = py_max3(fabs(theta), fabs(dx), fabs(dp));
+        gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+        if (stp > stx) gamma *= -1;
+        p = (gamma - dp) + theta;
+        q = ((gamma - dp) + gamma) + dx;
+        r = p / q;
+        stpc = stp + r * (stx - stp);
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+        else stpf = stpq;
+        brackt = true;
+    } else if (fabs(dp) < fabs(dx)) {
+        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
+        s = py_max3(fabs(theta), fabs(dx), fabs(dp));
+        gamma = s * sqrt(py_max2(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+        if (stp > stx) gamma = -gamma;
+        p = (gamma - dp) + theta;
+        q = (gamma + (dx - dp)) + gamma;
+        r = p / q;
+        if (r < 0 && gamma != 0) stpc = stp + r * (stx - stp);
+        else if (stp > stx) stpc = stpmax;
+        else stpc = stpmin;
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (brackt) {
+            if (fabs(stpc - stp) < fabs(stpq - stp)) stpf = stpc;
+            else stpf = stpq;
+            if (stp > stx) stpf = py_min2(stp + 0.66 * (sty - stp), stpf);
+            else stpf = py_max2(stp + 0.66 * (sty - stp), stpf);
+        } else {
+            if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+            else stpf = stpq;
+            stpf = np_clip(stpf, stpmin, stpmax);
+        }
+    } else {
+        if (brackt) {
+            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+            s = py_max3(fabs(theta), fabs(dy), fabs(dp));
+            gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+            if (stp > sty) gamma = -gamma;
+            p = (gamma - dp) + theta;
+            q = ((gamma - dp) + gamma) + dy;
+            r = p / q;
+            stpc = stp + r * (sty - stp);
+            stpf = stpc;
+        } else if (stp > stx) stpf = stpmax;
+        else stpf = stpmin;
+    }
+    if (fp > fx) {
+        sty = stp; fy = fp; dy = dp;
+    } else {
+        if (sgnd < 0) { sty = stx; fy = fx; dy = dx; }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stp = stpf;
+}
+
+// scipy/optimize/_linesearch.py:477-508 _cubicmin; false == None
+__device__ __forceinline__ bool cubicmin(double a, double fa, double fpa, double b, double fb,
+                                         double c, double fc, double &xmin) {
+    const double C = fpa, db = b - a, dc = c - a;
+    const double t = db * dc;
+    const double denom = (t * t) * (db - dc);
+    const double d00 = dc * dc, d01 = -(db * db), d10 = -(dc * dc * dc), d11 = db * db * db;
+    const double v0 = fb - fa - C * db, v1 = fc - fa - C * dc;
+    double A = d00 * v0 + d01 * v1, B = d10 * v0 + d11 * v1;
+    if (!finite_d(denom) || !finite_d(A) || !finite_d(B) || denom == 0.0) return false;
+    A /= denom; B /= denom;
+    const double radical = B * B - 3 * A * C;
+    if (!finite_d(A) || !finite_d(B) || !finite_d(radical) || radical < 0) return false;
+    const double den2 = 3 * A;
+    if (den2 == 0.0 || !finite_d(den2)) return false;
+    const double x = a + (-B + sqrt(radical)) / den2;
+    if (!finite_d(x)) return false;
+    xmin = x;
+    return true;
+}
+// scipy/optimize/_linesearch.py:511-529 _quadmin
+__device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double b, double fb,
+                                        double &xmin) {
+    const double D = fa, C = fpa, db = b - a * 1.0;
+    const double den = db * db;
+    const double num = fb - D - C * db;
+    if (den == 0.0 || !finite_d(den) || !finite_d(num)) return false;
+    const double B = num / den;
+    const double den2 = 2.0 * B;
+    if (den2 == 0.0 || !finite_d(den2)) return false;
+    const double x = a - C / den2;
+    if (!finite_d(x)) return false;
+    xmin = x;
+    return true;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
+    constexpr int KMAX = 64 * VPL;
+    __shared__ double se[KMAX + 1];  // exp(eta~ - m), broadcast to every lane
+    __shared__ double sv[KMAX + 1];  // vector broadcast (matvec operand / s)
+    __shared__ double sw[KMAX + 1];  // vector broadcast (w = H y)
+    const int lane = threadIdx.x;
+    const int K = P.K, n = P.n, NdPad = P.NdPad;
+    double *slab = P.slab_beta + (size_t)blockIdx.x * (size_t)(K + 2) * NdPad;
+    double *crow = slab + (size_t)K * NdPad;        // counts
+    double *wrow = slab + (size_t)(K + 1) * NdPad;  // counts / colsum(beta_d)
+    double *Hs = P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
+    const double *S = P.siginv;
+    const bool sdiag = P.siginv_diag != 0;
+
+    // one block (= one wavefront) per document; no work-queue loop: a single-wave workgroup has
+    // no hardware barrier, so cross-lane hand-offs through LDS must not straddle a loop back edge
+    {
+        const int64_t ticket = P.first + blockIdx.x;
+        if (ticket >= P.N) return;
+        const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
+        const int64_t p0 = P.indptr[doc];
+        const int Nd = (int)(P.indptr[doc + 1] - p0);
+        const int npass = (Nd + WAVE - 1) / WAVE;
+        const int asp = P.aspect ? P.aspect[doc] : 0;
+        const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
+
+        // ---- gather beta_d (stm.py:614-617) into the slab; assert beta >= 0 (stm.py:534)
+        double csum = 0.0;
+        bool bad = false;
+        for (int pass = 0; pass < npass; ++pass) {
+            const int v = pass * WAVE + lane;
+            if (v < Nd) {
+                const int idx = P.indices[p0 + v];
+                const double c = P.counts[p0 + v];
+                const double *row = bT + (size_t)idx * K;
+                double colsum = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    const double b = row[k];
+                    bad |= !(b >= 0.0);
+                    slab[(size_t)k * NdPad + v] = b;
+                    colsum += b;
+                }
+                crow[v] = c;
+                wrow[v] = c / colsum;
+                csum += c;
+            } else {
+                for (int k = 0; k < K; ++k) slab[(size_t)k * NdPad + v] = 0.0;
+                crow[v] = 0.0;
+                wrow[v] = 0.0;
+            }
+        }
+        __syncthreads();  // slab stores -> visible to the whole wave
+        if (wave_any(bad)) {
+            atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
+            return;
+        }
+        const double Ndoc = (double)(long long)wave_sum(csum);  // int(np.sum(word_count)), stm.py:933
+
+        // ---- lane vectors
+        double x[VPL], g[VPL], p[VPL], xt[VPL], gv[VPL], mu[VPL], sd[VPL], g0[VPL];
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) {
+            const int i = lane + WAVE * r;
+            const bool act = i < n;
+            x[r] = act ? P.eta[doc * n + i] : 0.0;
+            mu[r] = act ? P.mu[doc * n + i] : 0.0;
+            sd[r] = act ? S[(size_t)i * n + i] : 0.0;
+            g[r] = 0.0; p[r] = 0.0; xt[r] = 0.0; gv[r] = 0.0; g0[r] = 0.0;
+        }
+        // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
+        for (int k = 0; k < n; ++k) {
+            double t = 0.0;
+            for (int pass = 0; pass < npass; ++pass) {
+                const int v = pass * WAVE + lane;
+                t += slab[(size_t)k * NdPad + v] * wrow[v];
+            }
+            t = wave_sum(t);
+#pragma unroll
+            for (int r = 0; r < VPL; ++r)
+                if (k == lane + WAVE * r) g0[r] = t;
+        }
+
+        int nfev = 0, njev = 0;
+
+        // f(eta): stm.py:920-944
+        auto eval_F = [&]() -> double {
+            double mloc = 0.0;  // the appended 0 of eta~
+#pragma unroll
+            for (int r = 0; r < VPL; ++r)
+                if (lane + WAVE * r < n) mloc = nanmax(mloc, xt[r]);
+            const double m = wave_nanmax(mloc);
+            double cnt = 0.0, ssum = 0.0;
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) {
+                const int i = lane + WAVE * r;
+                if (i < K) {
+                    const double val = (i < n) ? xt[r] : 0.0;
+                    const double e = exp(val - m);
+                    se[i] = e;
+                    if (val == m) cnt += 1.0;
+                    else ssum += e;
+                }
+            }
+            __syncthreads();
+            cnt = wave_sum(cnt);
+            ssum = wave_sum(ssum);
+            // scipy.special.logsumexp: log1p(s/m) + log(m) + a_max
+            const double lse = log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
+            double part = 0.0;
+            for (int pass = 0; pass < npass; ++pass) {
+                const int v = pass * WAVE + lane;
+                const double *col = slab + v;
+                double s = 0.0;
+                for (int k = 0; k < K; ++k) s = fma(se[k], col[(size_t)k * NdPad], s);
+                if (v < Nd) part += crow[v] * (m + log(s));
+            }
+            part = wave_sum(part);
+            double q = 0.0;
+            if (sdiag) {
+#pragma unroll
+                for (int r = 0; r < VPL; ++r)
+                    if (lane + WAVE * r < n) {
+                        const double d = xt[r] - mu[r];
+                        q += (d * sd[r]) * d;
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < VPL; ++r)
+                    if (lane + WAVE * r < n) sv[lane + WAVE * r] = xt[r] - mu[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) {
+                    const int i = lane + WAVE * r;
+                    if (i < n) {
+                        double t = 0.0;
+                        for (int j = 0; j < n; ++j) t += sv[j] * S[(size_t)j * n + i];
+                        q += t * sv[i];
+                    }
+                }
+            }
+            q = wave_sum(q);
+            __syncthreads();
+            return 0.5 * q - (part - Ndoc * lse);
+        };
+
+        // df(eta): stm.py:946-958 (data term g0 has no eta dependence)
+        auto eval_DF = [&]() {
+            double ex[VPL];
+            double sl = 0.0;
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) {
+                ex[r] = (lane + WAVE * r < n) ? exp(xt[r]) : 0.0;
+                sl += ex[r];
+            }
+            const double sumexp = wave_sum(sl) + 1.0;  // + exp(0)
+            const double scale = Ndoc / sumexp;
+            if (sdiag) {
+#pragma unroll
+                for (int r = 0; r < VPL; ++r)
+                    gv[r] = (lane + WAVE * r < n) ? sd[r] * (xt[r] - mu[r]) - (g0[r] - scale * ex[r]) : 0.0;
+            } else {
+#pragma unroll
+                for (int r = 0; r < VPL; ++r)
+                    if (lane + WAVE * r < n) sv[lane + WAVE * r] = xt[r] - mu[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) {
+                    const int i = lane + WAVE * r;
+                    double t = 0.0;
+                    if (i < n)
+                        for (int j = 0; j < n; ++j) t += S[(size_t)i * n + j] * sv[j];
+                    gv[r] = (i < n) ? t - (g0[r] - scale * ex[r]) : 0.0;
+                }
+                __syncthreads();
+            }
+        };
+
+        auto dot = [&](const double (&a)[VPL], const double (&b)[VPL]) -> double {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) t += a[r] * b[r];
+            return wave_sum(t);
+        };
+        auto maxabs = [&](const double (&a)[VPL]) -> double {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) t = nanmax(t, fabs(a[r]));
+            return wave_nanmax(t);
+        };
+        // out_i = sum_j H[j][i] * vec_j  (H symmetric; row j is contiguous across lanes)
+        auto matvecH = [&](const double (&vec)[VPL], double (&out)[VPL]) {
+#pragma unroll
+            for (int r = 0; r < VPL; ++r)
+                if (lane + WAVE * r < n) sv[lane + WAVE * r] = vec[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) {
+                const int i = lane + WAVE * r;
+                double t = 0.0;
+                if (i < n)
+                    for (int j = 0; j < n; ++j) t += Hs[(size_t)j * n + i] * sv[j];
+                out[r] = t;
+            }
+            __syncthreads();
+        };
+
+        // ---- scipy _minimize_bfgs state (optimize/_optimize.py:1328-1502)
+        const double gtol = 1e-5, c1 = 1e-4, c2 = 0.9, amax = 1e100, amin = 1e-100, xtol = 1e-14;
+        const int maxiter = n * 200;
+        double old_fval = 0, old_old_fval = 0, gnorm = 0;
+        int k = 0, status = 0;
+        bool H_ident = true;
+        // line-search shared
+        double phi0 = 0, old_phi0 = 0, derphi0 = 0;
+        // DCSRCH state (optimize/_dcsrch.py)
+        double stx = 0, fx = 0, gx = 0, sty = 0, fy = 0, gy = 0, stmin = 0, stmax = 0, width = 0,
+               width1 = 0, finit = 0, ginit = 0, gtest = 0;
+        int stage = 1, w1_calls = 0;
+        bool brackt = false;
+        // wolfe2 / zoom state (optimize/_linesearch.py)
+        double alpha0 = 0, alpha1 = 0, phi_a0 = 0, phi_a1 = 0, derphi_a0 = 0;
+        int w2_i = 0;
+        double a_lo = 0, a_hi = 0, phi_lo = 0, phi_hi = 0, derphi_lo = 0, phi_rec = 0, a_rec = 0,
+               a_j = 0;
+        int zi = 0;
+        double acc_alpha = 0, acc_f = 0;
+        bool acc_have_g = false;
+        // evaluation request / result + scipy ScalarFunction's last-x cache
+        double alpha = 0.0, fval = 0, dval = 0, cache_f = 0;
+        bool want_eval = true, need_f = true, need_g = true;
+        bool have_x = false, f_ok = false, g_ok = false;
+        int st = S_INIT_DONE;
+
+        if (P.debug_flags & 1) st = S_FINISH;
+        long guard = 0;
+        while (st != S_FINISH) {
+            if (++guard > 400000L) { status = 1000 + st; break; }
+            if (want_eval) {
+                // xk + alpha * pk (separate multiply and add, like numpy)
+                double xn[VPL];
+                bool same = have_x;
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) {
+                    xn[r] = x[r] + alpha * p[r];
+                    same = same && (xn[r] == xt[r]);
+                }
+                same = wave_all(same);
+                if (!same) {
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) xt[r] = xn[r];
+                    have_x = true; f_ok = false; g_ok = false;
+                }
+                if (need_f) {
+                    if (!f_ok) { cache_f = eval_F(); f_ok = true; ++nfev; }
+                    fval = cache_f;
+                }
+                if (need_g) {
+                    if (!g_ok) { eval_DF(); g_ok = true; ++njev; }
+                    dval = dot(gv, p);
+                }
+                want_eval = false;
+            }
+            switch (st) {
+            case S_INIT_DONE: {
+                old_fval = fval;
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) g[r] = gv[r];
+                old_old_fval = old_fval + sqrt(dot(g, g)) / 2;
+                gnorm = maxabs(g);
+                st = S_OUTER_TOP;
+            } break;
+            case S_OUTER_TOP: {
+                if (!(gnorm > gtol && k < maxiter)) { st = S_FINISH; break; }
+                if (H_ident) {
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) p[r] = -g[r];
+                } else {
+                    double t[VPL];
+                    matvecH(g, t);
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) p[r] = -t[r];
+                }
+                derphi0 = dot(g, p);
+                phi0 = old_fval;
+                old_phi0 = old_old_fval;
+                st = S_W1_START;
+            } break;
+            case S_W1_START: {  // scalar_search_wolfe1 + DCSRCH START
+                double a1;
+                if (derphi0 != 0) {
+                    a1 = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
+                    if (a1 < 0) a1 = 1.0;
+                } else a1 = 1.0;
+                if (a1 < amin || a1 > amax || derphi0 >= 0) { st = S_W2_START; break; }  // ERROR
+                brackt = false; stage = 1; finit = phi0; ginit = derphi0; gtest = c1 * ginit;
+                width = amax - amin; width1 = width / 0.5;
+                stx = 0.0; fx = finit; gx = ginit; sty = 0.0; fy = finit; gy = ginit;
+                stmin = 0; stmax = a1 + 4.0 * a1;
+                w1_calls = 1;
+                if (!finite_d(a1)) { st = S_W2_START; break; }
+                alpha = a1; need_f = true; need_g = true; want_eval = true;
+                st = S_W1_ITER;
+            } break;
+            case S_W1_ITER: {  // DCSRCH._iterate with (stp, f, g) = (alpha, fval, dval)
+                ++w1_calls;
+                double stp = alpha;
+                const double f = fval, gd = dval;
+                const double ftest = finit + stp * gtest;
+                if (stage == 1 && f <= ftest && gd >= 0) stage = 2;
+                int task = 0;  // 0 FG, 1 CONVERGENCE, 2 WARNING
+                if (brackt && (stp <= stmin || stp >= stmax)) task = 2;
+                if (brackt && stmax - stmin <= xtol * stmax) task = 2;
+                if (stp == amax && f <= ftest && gd <= gtest) task = 2;
+                if (stp == amin && (f > ftest || gd >= gtest)) task = 2;
+                if (f <= ftest && fabs(gd) <= c2 * -ginit) task = 1;
+                if (task == 1) {
+                    acc_alpha = stp; acc_f = f; acc_have_g = true;
+                    st = S_ACCEPT;
+                    break;
+                }
+                if (task == 2) { st = S_W2_START; break; }
+                {
+                    const bool mod = (stage == 1 && f <= fx && f > ftest);
+                    double fm = f, fxm = fx, fym = fy, gm = gd, gxm = gx, gym = gy;
+                    if (mod) {
+                        fm = f - stp * gtest; fxm = fx - stx * gtest; fym = fy - sty * gtest;
+                        gm = gd - gtest; gxm = gx - gtest; gym = gy - gtest;
+                    }
+                    dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
+                    if (mod) {
+                        fx = fxm + stx * gtest; fy = fym + sty * gtest;
+                        gx = gxm + gtest; gy = gym + gtest;
+                    } else {
+                        fx = fxm; fy = fym; gx = gxm; gy = gym;
+                    }
+                }
+                if (brackt) {
+                    if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+                    width1 = width;
+                    width = fabs(sty - stx);
+                }
+                if (brackt) {
+                    stmin = py_min2(stx, sty);
+                    stmax = py_max2(stx, sty);
+                } else {
+                    stmin = stp + 1.1 * (stp - stx);
+                    stmax = stp + 4.0 * (stp - stx);
+                }
+                stp = np_clip(stp, amin, amax);
+                if ((brackt && (stp <= stmin || stp >= stmax)) ||
+                    (brackt && stmax - stmin <= xtol * stmax))
+                    stp = stx;
+                if (!finite_d(stp) || w1_calls >= 100) { st = S_W2_START; break; }
+                alpha = stp; need_f = true; need_g = true; want_eval = true;
+                st = S_W1_ITER;
+            } break;
+            case S_W2_START: {  // scalar_search_wolfe2 (optimize/_linesearch.py:341-474)
+                alpha0 = 0;
+                if (derphi0 != 0) alpha1 = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
+                else alpha1 = 1.0;
+                if (alpha1 < 0) alpha1 = 1.0;
+                alpha1 = py_min2(alpha1, amax);
+                alpha = alpha1; need_f = true; need_g = false; want_eval = true;
+                st = S_W2_FIRST;
+            } break;
+            case S_W2_FIRST: {
+                phi_a1 = fval; phi_a0 = phi0; derphi_a0 = derphi0; w2_i = 0;
+                st = S_W2_TOP;
+            } break;
+            case S_W2_TOP: {
+                if (w2_i >= 10) {  // bracketing loop exhausted: alpha returned, gradient None
+                    acc_alpha = alpha1; acc_f = phi_a1; acc_have_g = false;
+                    st = S_ACCEPT;
+                    break;
+                }
+                if (alpha1 == 0 || alpha0 > amax) { status = 2; st = S_FINISH; break; }
+                if (phi_a1 > phi0 + c1 * alpha1 * derphi0 || (phi_a1 >= phi_a0 && w2_i > 0)) {
+                    a_lo = alpha0; a_hi = alpha1; phi_lo = phi_a0; phi_hi = phi_a1; derphi_lo = derphi_a0;
+                    zi = 0; phi_rec = phi0; a_rec = 0;
+                    st = S_ZOOM_TOP;
+                    break;
+                }
+                alpha = alpha1; need_f = false; need_g = true; want_eval = true;
+                st = S_W2_GOT_G;
+            } break;
+            case S_W2_GOT_G: {
+                const double derphi_a1 = dval;
+                if (fabs(derphi_a1) <= -c2 * derphi0) {
+                    acc_alpha = alpha1; acc_f = phi_a1; acc_have_g = true;
+                    st = S_ACCEPT;
+                    break;
+                }
+                if (derphi_a1 >= 0) {
+                    a_lo = alpha1; a_hi = alpha0; phi_lo = phi_a1; phi_hi = phi_a0; derphi_lo = derphi_a1;
+                    zi = 0; phi_rec = phi0; a_rec = 0;
+                    st = S_ZOOM_TOP;
+                    break;
+                }
+                const double alpha2 = py_min2(2 * alpha1, amax);
+                alpha0 = alpha1; alpha1 = alpha2; phi_a0 = phi_a1; derphi_a0 = derphi_a1;
+                alpha = alpha1; need_f = true; need_g = false; want_eval = true;
+                st = S_W2_GOT_F;
+            } break;
+            case S_W2_GOT_F: {
+                phi_a1 = fval;
+                ++w2_i;
+                st = S_W2_TOP;
+            } break;
+            case S_ZOOM_TOP: {  // _zoom (optimize/_linesearch.py:532-621)
+                const double dalpha = a_hi - a_lo;
+                double a, b;
+                if (dalpha < 0) { a = a_hi; b = a_lo; } else { a = a_lo; b = a_hi; }
+                double cchk = 0;
+                bool have = false;
+                if (zi > 0) {
+                    cchk = 0.2 * dalpha;
+                    have = cubicmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, a_rec, phi_rec, a_j);
+                }
+                if (zi == 0 || !have || a_j > b - cchk || a_j < a + cchk) {
+                    const double qchk = 0.1 * dalpha;
+                    have = quadmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, a_j);
+                    if (!have || a_j > b - qchk || a_j < a + qchk) a_j = a_lo + 0.5 * dalpha;
+                }
+                alpha = a_j; need_f = true; need_g = false; want_eval = true;
+                st = S_ZOOM_GOT_F;
+            } break;
+            case S_ZOOM_GOT_F: {
+                const double phi_aj = fval;
+                if (phi_aj > phi0 + c1 * a_j * derphi0 || phi_aj >= phi_lo) {
+                    phi_rec = phi_hi; a_rec = a_hi; a_hi = a_j; phi_hi = phi_aj;
+                    st = S_ZOOM_NEXT;
+                    break;
+                }
+                alpha = a_j; need_f = false; need_g = true; want_eval = true;
+                st = S_ZOOM_GOT_G;
+            } break;
+            case S_ZOOM_GOT_G: {
+                const double derphi_aj = dval;
+                const double phi_aj = fval;  // value at a_j from S_ZOOM_GOT_F (unchanged)
+                if (fabs(derphi_aj) <= -c2 * derphi0) {
+                    acc_alpha = a_j; acc_f = phi_aj; acc_have_g = true;
+                    st = S_ACCEPT;
+                    break;
+                }
+                if (derphi_aj * (a_hi - a_lo) >= 0) {
+                    phi_rec = phi_hi; a_rec = a_hi; a_hi = a_lo; phi_hi = phi_lo;
+                } else {
+                    phi_rec = phi_lo; a_rec = a_lo;
+                }
+                a_lo = a_j; phi_lo = phi_aj; derphi_lo = derphi_aj;
+                st = S_ZOOM_NEXT;
+            } break;
+            case S_ZOOM_NEXT: {
+                ++zi;
+                if (zi > 10) { status = 2; st = S_FINISH; break; }
+                st = S_ZOOM_TOP;
+            } break;
+            case S_ACCEPT: {
+                if (!acc_have_g) {  // gfkp1 is None -> myfprime(xkp1)
+                    alpha = acc_alpha; need_f = false; need_g = true; want_eval = true;
+                }
+                st = S_ACCEPT2;
+            } break;
+            case S_ACCEPT2: {
+                double s[VPL], y[VPL];
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) {
+                    s[r] = acc_alpha * p[r];
+                    x[r] = x[r] + s[r];
+                    y[r] = gv[r] - g[r];
+                    g[r] = gv[r];
+                }
+                ++k;
+                old_old_fval = phi0;
+                old_fval = acc_f;
+                gnorm = maxabs(g);
+                if (gnorm <= gtol) { st = S_FINISH; break; }
+                if (acc_alpha * sqrt(dot(p, p)) <= 0.0) { st = S_FINISH; break; }  // xrtol = 0
+                if (!finite_d(old_fval)) { status = 2; st = S_FINISH; break; }
+                const double rhok_inv = dot(y, s);
+                const double rhok = (rhok_inv == 0.0) ? 1000.0 : 1.0 / rhok_inv;
+                // H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T, expanded (H symmetric):
+                //   H - rho (s w^T + w s^T) + (rho^2 y^T w + rho) s s^T,  w = H y
+                double w[VPL];
+                if (H_ident) {
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) w[r] = y[r];
+                } else matvecH(y, w);
+                const double yHy = dot(y, w);
+                const double cc = rhok * rhok * yHy + rhok;
+#pragma unroll
+                for (int r = 0; r < VPL; ++r)
+                    if (lane + WAVE * r < n) { sv[lane + WAVE * r] = s[r]; sw[lane + WAVE * r] = w[r]; }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) {
+                    const int j = lane + WAVE * r;
+                    if (j < n) {
+                        const double sj = s[r], wj = w[r];
+                        for (int i = 0; i < n; ++i) {
+                            const double h = H_ident ? (i == j ? 1.0 : 0.0) : Hs[(size_t)i * n + j];
+                            const double si = sv[i], wi = sw[i];
+                            Hs[(size_t)i * n + j] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
+                        }
+                    }
+                }
+                __syncthreads();
+                H_ident = false;
+                st = S_OUTER_TOP;
+            } break;
+            default: st = S_FINISH; break;
+            }
+        }
+        if (status == 0) {
+            if (k >= maxiter) status = 1;
+            else {
+                bool anynan = (gnorm != gnorm) || (old_fval != old_fval);
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) anynan |= (x[r] != x[r]);
+                if (wave_any(anynan)) status = 3;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) {
+            const int i = lane + WAVE * r;
+            if (i < n) P.eta[doc * n + i] = x[r];
+        }
+        // uniform stores (every lane writes the same word)
+        if (P.status) P.status[doc] = status;
+        if (P.nit) P.nit[doc] = k;
+        if (P.nfev) P.nfev[doc] = nfev;
+        if (P.njev) P.njev[doc] = njev;
+    }
+}
+
+}  // namespace stm

@@ -1,0 +1,222 @@
+"""Device engine: a thin object over one `stm_handle` (one GPU, one HIP stream).
+
+Holds the packed corpus (CSR), beta, eta, mu, theta and the sufficient
+statistics resident in HBM and runs the E-step kernels.  Used by
+strutopy_amd.stm.STM; nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dptr, f64, iptr, lptr
+
+
+class HipEstepEngine:
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        check(self._L.stm_create(C.byref(self._h), int(device)))
+        self.device = int(device)
+        self.N = self.V = self.K = self.A = 0
+        self.indptr = None
+
+    # -- lifetime -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.stm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        hbm = C.c_int64(0)
+        check(self._L.stm_device_info(self._h, name, 256, C.byref(cu), C.byref(hbm)))
+        return dict(name=name.value.decode(), cu=cu.value, hbm_bytes=hbm.value)
+
+    # -- corpus / model state ---------------------------------------------------------
+    def set_corpus(self, indptr, indices, counts, V, aspect=None, A=1):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        counts = f64(counts)
+        asp = None
+        if aspect is not None and A > 1:
+            asp = np.ascontiguousarray(aspect, dtype=np.int32)
+        check(self._L.stm_set_corpus(self._h, len(indptr) - 1, int(V), lptr(indptr), iptr(indices),
+                                     dptr(counts), iptr(asp) if asp is not None else None, int(A)))
+        self.N, self.V, self.A = len(indptr) - 1, int(V), int(max(A, 1))
+        self.indptr = indptr
+
+    def set_topics(self, K):
+        check(self._L.stm_set_topics(self._h, int(K)))
+        self.K = int(K)
+
+    def _beta_shape(self):
+        return (self.K, self.V) if self.A == 1 else (self.A, self.K, self.V)
+
+    def put_beta(self, beta):
+        beta = f64(beta)
+        if beta.shape != self._beta_shape():
+            raise ValueError(f"beta has shape {beta.shape}, expected {self._beta_shape()}")
+        check(self._L.stm_put_beta(self._h, dptr(beta)))
+
+    def put_eta(self, eta):
+        eta = f64(eta).reshape(self.N, self.K - 1)
+        check(self._L.stm_put_eta(self._h, dptr(eta)))
+
+    def put_mu(self, mu):
+        mu = f64(mu).reshape(self.N, self.K - 1)
+        check(self._L.stm_put_mu(self._h, dptr(mu)))
+
+    def _get(self, fn, shape):
+        out = np.empty(shape, dtype=np.float64)
+        check(fn(self._h, dptr(out)))
+        return out
+
+    def get_beta(self):
+        return self._get(self._L.stm_get_beta, self._beta_shape())
+
+    def get_eta(self):
+        return self._get(self._L.stm_get_eta, (self.N, self.K - 1))
+
+    def get_mu(self):
+        return self._get(self._L.stm_get_mu, (self.N, self.K - 1))
+
+    def get_theta(self):
+        return self._get(self._L.stm_get_theta, (self.N, self.K))
+
+    def get_sigma_ss(self):
+        return self._get(self._L.stm_get_sigma_ss, (self.K - 1, self.K - 1))
+
+    def get_beta_ss(self):
+        return self._get(self._L.stm_get_beta_ss, self._beta_shape())
+
+    def get_bound_docs(self):
+        return self._get(self._L.stm_get_bound_docs, (self.N,))
+
+    def get_phi_last(self):
+        nd = int(self.indptr[-1] - self.indptr[-2])
+        out = np.empty((self.K, nd))
+        check(self._L.stm_get_phi(self._h, self.N - 1, dptr(out)))
+        return out
+
+    def get_diagnostics(self):
+        out = {k: np.empty(self.N, dtype=np.int32) for k in ("status", "nit", "nfev", "njev", "pd_path")}
+        check(self._L.stm_get_diagnostics(self._h, *(iptr(out[k]) for k in ("status", "nit", "nfev", "njev", "pd_path"))))
+        return out
+
+    def debug_mats(self):
+        n = self.K - 1
+        hess, chol, nu = (np.empty((self.N, n, n)) for _ in range(3))
+        check(self._L.stm_debug_get_mats(self._h, dptr(hess), dptr(chol), dptr(nu)))
+        return hess, chol, nu
+
+    # -- the hot path -----------------------------------------------------------------
+    def estep(self, siginv, sigmaentropy):
+        """Run the E-step kernels on the resident state; returns the summed bound."""
+        siginv = f64(siginv).reshape(self.K - 1, self.K - 1)
+        tot = C.c_double(0.0)
+        check(self._L.stm_estep(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot)))
+        return tot.value
+
+    def kernel_ms(self):
+        ms = (C.c_float * 3)()
+        check(self._L.stm_last_kernel_ms(self._h, ms))
+        return dict(solver=ms[0], post=ms[1], estep=ms[2])
+
+    def synchronize(self):
+        check(self._L.stm_synchronize(self._h))
+
+    # -- M-step pieces ---------------------------------------------------------------
+    def put_covariates(self, X):
+        X = f64(X).reshape(self.N, -1)
+        check(self._L.stm_put_covariates(self._h, dptr(X), X.shape[1]))
+        self.p = X.shape[1]
+
+    def moments(self, p):
+        n = self.K - 1
+        L = 1 + p + n + p * p + p * n
+        out = np.zeros(L)
+        check(self._L.stm_mstep_moments(self._h, dptr(out), L))
+        return out
+
+    def set_mu_regression(self, gamma):
+        gamma = f64(gamma)
+        check(self._L.stm_mstep_set_mu(self._h, dptr(gamma), None))
+
+    def set_mu_constant(self, mean_eta):
+        mean_eta = f64(mean_eta)
+        check(self._L.stm_mstep_set_mu(self._h, None, dptr(mean_eta)))
+
+    def covariance(self):
+        return self._get(self._L.stm_mstep_covariance, (self.K - 1, self.K - 1))
+
+    def update_beta(self):
+        check(self._L.stm_mstep_update_beta(self._h))
+
+    # -- multi-GPU ---------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        check(self._L.stm_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        buf = C.create_string_buffer(uid, 128)
+        check(self._L.stm_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def allreduce_suffstats(self, extra):
+        """All-reduce [bound | sigma_ss | extra | beta_ss] over the ranks; returns (bound, extra)."""
+        extra = f64(extra).copy()
+        tot = C.c_double(0.0)
+        check(self._L.stm_allreduce_suffstats(self._h, C.byref(tot), dptr(extra), len(extra)))
+        return tot.value, extra
+
+    def allreduce_small(self, buf):
+        buf = f64(buf).copy()
+        flat = buf.reshape(-1)
+        check(self._L.stm_allreduce_small(self._h, dptr(flat), flat.size))
+        return buf
+
+
+def estep_host(indptr, indices, counts, beta, mu, eta, siginv, sigmaentropy, aspect=None, device=0):
+    """One-shot E-step over host arrays through stm_estep_host (upload, run, download)."""
+    L = _lib.lib()
+    beta = f64(beta)
+    if beta.ndim == 2:
+        A, (K, V) = 1, beta.shape
+    else:
+        A, K, V = beta.shape
+    n = K - 1
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    counts = f64(counts)
+    N = len(indptr) - 1
+    mu = f64(mu).reshape(N, n)
+    eta = f64(eta).reshape(N, n).copy()
+    siginv = f64(siginv).reshape(n, n)
+    out = dict(eta=eta, theta=np.zeros((N, K)), bound_doc=np.zeros(N), sigma_ss=np.zeros((n, n)),
+               beta_ss=np.zeros_like(beta))
+    for k in ("status", "nit", "nfev", "njev", "pd_path"):
+        out[k] = np.zeros(N, dtype=np.int32)
+    tot = np.zeros(1)
+    a = _lib.EstepArgs()
+    a.N, a.K, a.V, a.A = N, K, V, A
+    a.indptr, a.indices, a.counts = lptr(indptr), iptr(indices), dptr(counts)
+    if aspect is not None and A > 1:
+        aspect = np.ascontiguousarray(aspect, dtype=np.int32)
+        a.aspect = iptr(aspect)
+    a.beta, a.mu, a.eta, a.siginv = dptr(beta), dptr(mu), dptr(eta), dptr(siginv)
+    a.sigmaentropy = float(sigmaentropy)
+    a.theta, a.bound, a.sigma_ss, a.beta_ss, a.bound_total = (
+        dptr(out["theta"]), dptr(out["bound_doc"]), dptr(out["sigma_ss"]), dptr(out["beta_ss"]), dptr(tot))
+    for k in ("status", "nit", "nfev", "njev", "pd_path"):
+        setattr(a, k, iptr(out[k]))
+    check(L.stm_estep_host(C.byref(a), int(device)))
+    out["bound"] = float(tot[0])
+    return out
