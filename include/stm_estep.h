@@ -73,6 +73,9 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
 int stm_get_sigma_ss(stm_handle *h, double *sigma_ss /* [(K-1)^2] */);
 int stm_get_beta_ss(stm_handle *h, double *beta_ss /* [A][K][V] */);
 int stm_get_bound_docs(stm_handle *h, double *bound /* [N] */);
+/* overwrite the device-resident sufficient statistics (host-side reduction fallback) */
+int stm_put_sigma_ss(stm_handle *h, const double *sigma_ss /* [(K-1)^2] */);
+int stm_put_beta_ss(stm_handle *h, const double *beta_ss /* [A][K][V] */);
 /* per-document solver diagnostics of the last E-step (any pointer may be NULL):
  * scipy OptimizeResult.status / .nit, evaluation counts, PD-fix path
  * (0 none, 1 make_pd, 2 make_pd + 1e-5; stm.py:1017-1021) */

@@ -905,8 +905,16 @@ int stm_oracle_estep(const stm_oracle_args *a, int nthreads) {
         }
         free(betad); free(work); free(wK); free(phi); free(Hm);
     }
+    /* reduce the per-thread partials in thread order (parallel over the entries) */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+    for (int64_t q = 0; q < (int64_t)KV; ++q) {
+        double t_ = a->beta_ss[q];
+        for (int t = 1; t < nt; ++t) t_ += bss[t][q];
+        a->beta_ss[q] = t_;
+    }
     for (int t = 1; t < nt; ++t) {
-        for (size_t q = 0; q < KV; ++q) a->beta_ss[q] += bss[t][q];
         for (size_t q = 0; q < (size_t)n * n; ++q) a->sigma_ss[q] += sss[t][q];
         free(bss[t]); free(sss[t]);
     }

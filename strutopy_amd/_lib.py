@@ -52,6 +52,8 @@ SIGNATURES = {
     "stm_get_sigma_ss": (C.c_int, [_h, _dp]),
     "stm_get_beta_ss": (C.c_int, [_h, _dp]),
     "stm_get_bound_docs": (C.c_int, [_h, _dp]),
+    "stm_put_sigma_ss": (C.c_int, [_h, _dp]),
+    "stm_put_beta_ss": (C.c_int, [_h, _dp]),
     "stm_get_diagnostics": (C.c_int, [_h, _ip, _ip, _ip, _ip, _ip]),
     "stm_get_phi": (C.c_int, [_h, C.c_int64, _dp]),
     "stm_estep_host": (C.c_int, [C.POINTER(EstepArgs), C.c_int]),

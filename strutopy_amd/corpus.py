@@ -1,0 +1,162 @@
+"""Corpus packing and the streaming synthetic-corpus generator.
+
+* ``pack_bow`` turns the reference's document format -- a list of lists of
+  ``(word_id, count)`` tuples (gensim BoW; reference src/modules/stm.py:331-332,
+  unpacked per document per iteration at stm.py:522-533) -- into one CSR triple
+  that is uploaded to HBM once.
+* ``synthetic_corpus`` follows the data-generating process of the reference's
+  ``CorpusCreation`` (src/modules/generate_docs.py: beta_k ~ Dir(0.05) :180,
+  gamma ~ N(m, 0.001 I) :194-200, x_d in {0,1}^level :207-212,
+  eta_d ~ N(x_d gamma^T, 0.001 I) :221-228, theta = softmax([eta, 0]) :268-271,
+  words ~ Multinomial(n_words, theta beta) :297-302, unused terms dropped and
+  ids re-assigned in order of first appearance :304-316) without materialising
+  the dense N x V probability matrix (generate_docs.py:297), so it scales to the
+  100k / 1M document configurations.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class PackedCorpus:
+    """CSR form of a bag-of-words corpus."""
+    indptr: np.ndarray   # int64 [N+1]
+    indices: np.ndarray  # int32 [nnz], unique within a document
+    counts: np.ndarray   # float64 [nnz]
+    V: int
+
+    @property
+    def N(self):
+        return len(self.indptr) - 1
+
+    @property
+    def nnz(self):
+        return int(self.indptr[-1])
+
+    def __len__(self):
+        return self.N
+
+    def slice(self, lo, hi):
+        """Documents [lo, hi) as an independent PackedCorpus (same vocabulary)."""
+        a, b = int(self.indptr[lo]), int(self.indptr[hi])
+        return PackedCorpus((self.indptr[lo:hi + 1] - a).astype(np.int64), self.indices[a:b].copy(),
+                            self.counts[a:b].copy(), self.V)
+
+    def to_bow(self):
+        """Back to the reference's list-of-lists-of-tuples format."""
+        docs = []
+        for i in range(self.N):
+            sl = slice(self.indptr[i], self.indptr[i + 1])
+            docs.append(list(zip(self.indices[sl].tolist(), self.counts[sl].astype(np.int64).tolist())))
+        return docs
+
+    def word_counts(self):
+        """Corpus-wide word totals (what stm.py:485-486 derives from create_dtm)."""
+        return np.bincount(self.indices, weights=self.counts, minlength=self.V)
+
+
+def pack_bow(documents, V=None):
+    """list[list[(word_id, count)]] -> PackedCorpus.  Mirrors np.array(doc) of stm.py:522."""
+    if isinstance(documents, PackedCorpus):
+        return documents
+    N = len(documents)
+    lens = np.fromiter((len(d) for d in documents), dtype=np.int64, count=N)
+    if N and lens.min() < 1:
+        raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
+    indptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    counts = np.empty(nnz, dtype=np.float64)
+    pos = 0
+    for d in documents:
+        arr = np.asarray(d)
+        k = arr.shape[0]
+        indices[pos:pos + k] = arr[:, 0]
+        counts[pos:pos + k] = arr[:, 1]
+        pos += k
+    vmax = int(indices.max()) + 1 if nnz else 0
+    if V is None:
+        V = vmax
+    elif vmax > V:
+        raise IndexError(f"word id {vmax - 1} is out of range for a dictionary of length {V}")
+    return PackedCorpus(indptr, indices, counts, int(V))
+
+
+@dataclass
+class SyntheticCorpus:
+    corpus: PackedCorpus
+    X: np.ndarray          # [N, level] 0/1 prevalence covariates (the generator's `metadata`)
+    beta_true: np.ndarray  # [K, V_requested]
+    gamma_true: np.ndarray
+    V_requested: int
+
+
+def synthetic_corpus(n_docs, V, K, n_words=150, level=1, seed=12345, remove_terms=True, chunk=20000):
+    """STM data-generating process of the reference's CorpusCreation, streamed.
+
+    A multinomial draw of ``n_words`` from the mixture ``theta_d @ beta`` equals
+    ``n_words`` i.i.d. draws of (topic ~ theta_d, word ~ beta_topic); sampling the
+    pairs directly avoids the dense N x V matrix.
+    """
+    rng = np.random.default_rng(seed)
+    beta = rng.dirichlet(np.repeat(0.05, V), size=K)
+    mean = rng.standard_normal(level)
+    mean = rng.multivariate_normal(mean, np.diag(np.full(level, 0.001)))
+    gamma = rng.multivariate_normal(mean, np.diag(np.full(level, 0.001)), K - 1)  # (K-1) x level
+    X = rng.integers(0, 2, size=(n_docs, level))
+    cdf_beta = np.cumsum(beta, axis=1)
+    cdf_beta[:, -1] = 1.0
+    all_idx, all_cnt, lens = [], [], []
+    for lo in range(0, n_docs, chunk):
+        hi = min(n_docs, lo + chunk)
+        m = hi - lo
+        eta = X[lo:hi] @ gamma.T + rng.normal(0.0, np.sqrt(0.001), size=(m, K - 1))
+        eta_ = np.concatenate([eta, np.zeros((m, 1))], axis=1)
+        eta_ -= eta_.max(axis=1, keepdims=True)
+        theta = np.exp(eta_)
+        theta /= theta.sum(axis=1, keepdims=True)
+        cdf_theta = np.cumsum(theta, axis=1)
+        cdf_theta[:, -1] = 1.0
+        u = rng.random((m, n_words))
+        # topic of every token: one flat searchsorted over row-offset CDFs
+        rows = np.arange(m, dtype=np.float64)[:, None]
+        z = np.searchsorted((cdf_theta + rows).ravel(), (u + rows).ravel(), side="right").reshape(m, n_words)
+        z -= (np.arange(m) * K)[:, None]
+        np.clip(z, 0, K - 1, out=z)
+        u2 = rng.random((m, n_words))
+        w = np.empty((m, n_words), dtype=np.int64)
+        for k in range(K):
+            sel = z == k
+            if sel.any():
+                w[sel] = np.searchsorted(cdf_beta[k], u2[sel], side="right")
+        np.clip(w, 0, V - 1, out=w)
+        w.sort(axis=1)
+        # run-length encode every row
+        new = np.ones((m, n_words), dtype=bool)
+        new[:, 1:] = w[:, 1:] != w[:, :-1]
+        flat_new = new.ravel()
+        starts = np.flatnonzero(flat_new)
+        ends = np.append(starts[1:], m * n_words)
+        all_idx.append(w.ravel()[starts])
+        all_cnt.append((ends - starts).astype(np.float64))
+        lens.append(new.sum(axis=1))
+    idx = np.concatenate(all_idx)
+    cnt = np.concatenate(all_cnt)
+    lens = np.concatenate(lens)
+    indptr = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    V_eff = V
+    if remove_terms:
+        # generate_docs.py:304-316: ids are re-assigned in order of first appearance
+        first = np.full(V, np.iinfo(np.int64).max, dtype=np.int64)
+        np.minimum.at(first, idx, np.arange(len(idx)))
+        used = np.flatnonzero(first != np.iinfo(np.int64).max)
+        order = used[np.argsort(first[used], kind="stable")]
+        remap = np.full(V, -1, dtype=np.int64)
+        remap[order] = np.arange(len(order))
+        idx = remap[idx]
+        V_eff = len(order)
+    corpus = PackedCorpus(indptr, idx.astype(np.int32), cnt, int(V_eff))
+    return SyntheticCorpus(corpus, X.astype(np.float64), beta, gamma, V)

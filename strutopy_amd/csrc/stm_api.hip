@@ -327,6 +327,16 @@ int stm_get_eta(stm_handle *h, double *eta) { NEED_MODEL(h); return get_vec(h, e
 int stm_get_mu(stm_handle *h, double *mu) { NEED_MODEL(h); return get_vec(h, mu, h->d_mu, (size_t)h->N * h->n); }
 int stm_get_theta(stm_handle *h, double *theta) { NEED_MODEL(h); return get_vec(h, theta, h->d_theta, (size_t)h->N * h->K); }
 int stm_get_sigma_ss(stm_handle *h, double *s) { NEED_MODEL(h); return get_vec(h, s, h->d_sigma_ss, (size_t)h->n * h->n); }
+int stm_put_sigma_ss(stm_handle *h, const double *s) { NEED_MODEL(h); return put_vec(h, h->d_sigma_ss, s, (size_t)h->n * h->n); }
+int stm_put_beta_ss(stm_handle *h, const double *beta_ss) {
+    NEED_MODEL(h);
+    if (!beta_ss) return fail(STM_ERR_INVALID, "beta_ss is NULL");
+    const size_t KV = (size_t)h->A * h->K * h->V;
+    HIP_TRY(hipMemcpyAsync(h->d_tmpKV, beta_ss, sizeof(double) * KV, hipMemcpyHostToDevice, h->stream));
+    if (int rc = transpose3(h, h->d_tmpKV, h->d_beta_ssT, h->K, h->V)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
 int stm_get_bound_docs(stm_handle *h, double *b) { NEED_MODEL(h); return get_vec(h, b, h->d_bound, (size_t)h->N); }
 
 int stm_get_diagnostics(stm_handle *h, int32_t *status, int32_t *nit, int32_t *nfev, int32_t *njev, int32_t *pd_path) {

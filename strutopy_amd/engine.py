@@ -20,6 +20,7 @@ class HipEstepEngine:
         self.device = int(device)
         self.N = self.V = self.K = self.A = 0
         self.indptr = None
+        self.last_bound = 0.0
 
     # -- lifetime -----------------------------------------------------------------
     def close(self):
@@ -97,6 +98,17 @@ class HipEstepEngine:
     def get_beta_ss(self):
         return self._get(self._L.stm_get_beta_ss, self._beta_shape())
 
+    def put_sigma_ss(self, s):
+        s = f64(s).reshape(self.K - 1, self.K - 1)
+        check(self._L.stm_put_sigma_ss(self._h, dptr(s)))
+
+    def put_beta_ss(self, b):
+        b = f64(b).reshape(self._beta_shape())
+        check(self._L.stm_put_beta_ss(self._h, dptr(b)))
+
+    def get_bound_total(self):
+        return self.last_bound
+
     def get_bound_docs(self):
         return self._get(self._L.stm_get_bound_docs, (self.N,))
 
@@ -123,6 +135,7 @@ class HipEstepEngine:
         siginv = f64(siginv).reshape(self.K - 1, self.K - 1)
         tot = C.c_double(0.0)
         check(self._L.stm_estep(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot)))
+        self.last_bound = tot.value
         return tot.value
 
     def kernel_ms(self):

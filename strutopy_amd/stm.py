@@ -1,0 +1,416 @@
+"""`STM` -- drop-in for the hot path of strutopy's STM class on MI355X.
+
+Mirrors the method surface of the reference class (reference
+src/modules/stm.py:310-1149): same constructor keywords (stm.py:311-329), same
+attributes (`beta, mu, eta, sigma, theta, gamma, bound, last_bounds, siginv,
+sigmaentropy, phi, wcounts, N, K, V, A`), `E_step()` -> `(beta_ss, sigma_ss)`
+(stm.py:489-597), `M_step(beta_ss, sigma_ss)` (stm.py:622-747),
+`expectation_maximization(saving, output_dir)` (stm.py:855-880; also reachable
+as `fit()`), `EM_is_converged`, `max_its_reached`, `save_model` (stm.py:1120).
+
+The E-step runs in hand-written HIP kernels behind the C-ABI of
+include/stm_estep.h; host code is Python + NumPy + ctypes.  There is no CPU
+fallback: constructing an STM without a usable GPU / built library raises.
+
+Out of scope (raise NotImplementedError): spectral initialisation
+(stm.py:30-296, needs the absent `qpsolvers`), `mnreg` (`lda_beta=False`,
+stm.py:749-853, broken in the reference on current scipy), labelling/plot helpers.
+"""
+import logging
+import os
+import pickle
+import time
+
+import numpy as np
+
+from .corpus import PackedCorpus, pack_bow
+from .dist import SingleComm
+
+logger = logging.getLogger(__name__)
+
+
+def _default_engine(device):
+    from .engine import HipEstepEngine  # raises if libstm_hip.so / a GPU is missing
+    return HipEstepEngine(device)
+
+
+def encode_covariates(X):
+    """The covariate preparation of update_mu (stm.py:656-671): 2-D, one-hot unless already 0/1."""
+    if X is None:
+        return None
+    try:
+        import pandas as pd  # stm.py:657 tries `.astype("category")` (a pandas-only no-op here)
+        if isinstance(X, (pd.DataFrame, pd.Series)):
+            X = X.to_numpy()
+    except Exception:
+        pass
+    prev_cov = np.array(X)[:, None]
+    if prev_cov.ndim > 2:
+        prev_cov = np.squeeze(prev_cov, axis=1)
+    if not np.array_equal(prev_cov, prev_cov.astype(bool)):
+        # sklearn OneHotEncoder semantics: per column, sorted categories -> indicator columns
+        cols = []
+        for j in range(prev_cov.shape[1]):
+            cats = np.unique(prev_cov[:, j])
+            cols.append((prev_cov[:, j][:, None] == cats[None, :]).astype(np.float64))
+        prev_cov = np.concatenate(cols, axis=1)
+    return np.ascontiguousarray(prev_cov, dtype=np.float64)
+
+
+class STM:
+    def __init__(self, documents, dictionary, content, K, X, kappa_interactions, max_em_iter,
+                 sigma_prior, convergence_threshold, lda_beta=True, beta_index=None, A=None,
+                 dtype=np.float32, init_type="spectral", model_type="STM", mode="ols",
+                 device=0, comm=None, engine=None, n_total=None):
+        """Same arguments as the reference constructor (stm.py:311-329) plus
+
+        device  : GPU ordinal of this process
+        comm    : strutopy_amd.dist communicator when `documents` is one shard of a
+                  document-sharded corpus (None: single GPU)
+        engine  : test hook -- an object with the HipEstepEngine interface
+        `documents` may be the reference's BoW list or a strutopy_amd.corpus.PackedCorpus.
+        """
+        np.random.seed(123456)  # stm.py:361 reseeds numpy's legacy global RNG; kept for drop-in parity
+        self.dtype = np.finfo(dtype).dtype
+
+        self.documents = documents
+        self.dictionary = dictionary
+        self.init = init_type
+        self.model = model_type
+        self.mode = mode
+        self.content = content
+        self.K = K
+        self.A = A
+        self.V = len(self.dictionary) if dictionary is not None else int(documents.V)
+        self.X = X
+        self.interactions = kappa_interactions
+        self.beta_index = beta_index
+        self.max_em_iter = max_em_iter
+        self.sigma_prior = sigma_prior
+        self.convergence_threshold = convergence_threshold
+        self.N = len(self.documents)
+        self.LDAbeta = lda_beta
+        self.betaindex = beta_index
+        self.last_bounds = []
+        self.max_em_its = max_em_iter
+        if self.K == 0:
+            raise ValueError("Number of topics must be specified")
+        if self.A == 1:
+            logging.warning("no dimension for the topical content provided")
+
+        self.comm = comm if comm is not None else SingleComm()
+        self.N_total = int(n_total) if n_total is not None else int(
+            self.comm.allreduce_host(np.array([float(self.N)]))[0])
+
+        # ---- device state
+        self._corpus = pack_bow(documents, V=self.V)
+        self._levels = int(self.A) if (self.interactions and self.A) else 1
+        self._aspect = None
+        if self._levels > 1:
+            if beta_index is None:
+                raise ValueError("kappa_interactions=True needs beta_index")
+            self._aspect = np.ascontiguousarray(beta_index, dtype=np.int32)
+        self._engine = engine if engine is not None else _default_engine(device)
+        self._engine.set_corpus(self._corpus.indptr, self._corpus.indices, self._corpus.counts, self.V,
+                                aspect=self._aspect, A=self._levels)
+        self._engine.set_topics(self.K)
+        self.comm.attach(self._engine)
+        self._Xenc = encode_covariates(X) if model_type == "STM" else None
+        if self._Xenc is not None and len(self._Xenc) != self.N:
+            raise ValueError("X must have one row per document")
+        self._cov_on_device = False
+        # which side holds the fresh copy of each array ("host" | "device" | "both")
+        self._fresh = dict(beta="host", eta="host", mu="host", theta="host")
+        self.init_params()
+        self.timings = []
+
+    # ------------------------------------------------------------------ state plumbing
+    def _host_value(self, name):
+        if self._fresh[name] == "device":
+            getter = getattr(self._engine, "get_" + name)
+            setattr(self, "_" + name, getter())
+            self._fresh[name] = "both"
+        return getattr(self, "_" + name)
+
+    def _set_host(self, name, value):
+        setattr(self, "_" + name, value)
+        self._fresh[name] = "host"
+
+    def _push(self, name):
+        if self._fresh[name] == "host":
+            getattr(self._engine, "put_" + name)(getattr(self, "_" + name))
+            self._fresh[name] = "both"
+
+    beta = property(lambda s: s._host_value("beta"), lambda s, v: s._set_host("beta", v))
+    eta = property(lambda s: s._host_value("eta"), lambda s, v: s._set_host("eta", v))
+    mu = property(lambda s: s._host_value("mu"), lambda s, v: s._set_host("mu", v))
+
+    @property
+    def theta(self):
+        return self._host_value("theta")
+
+    @theta.setter
+    def theta(self, v):
+        self._theta = v
+        self._fresh["theta"] = "both"  # theta is an output only
+
+    # ------------------------------------------------------------------ initialisation (stm.py:402-486)
+    def init_params(self):
+        self.init_beta()
+        self.init_mu()
+        self.init_eta()
+        self.init_sigma()
+        self.wcounts = self._corpus.word_counts()
+        self.init_theta()
+
+    def init_beta(self):
+        if self.init == "spectral":
+            raise NotImplementedError(
+                "spectral initialisation (reference stm.py:30-296) is outside the accelerated hot path; "
+                "use init_type='random' or assign `model.beta` before fitting")
+        elif self.init == "random":
+            # stm.py:425-439, numpy legacy RNG stream seeded at stm.py:361
+            beta_init = np.random.gamma(0.1, 1, self.V * self.K).reshape(self.K, self.V)
+            row_sums = np.sum(beta_init, axis=1)[:, None]
+            beta_init_normalized = np.divide(beta_init, row_sums, out=np.zeros_like(beta_init),
+                                             where=row_sums != 0)
+            if self.interactions:
+                self.beta = np.repeat(beta_init_normalized[None, :], self.A, axis=0)
+            else:
+                self.beta = beta_init_normalized
+        else:
+            raise ValueError("init_type must be 'random' or 'spectral'")
+
+    def init_mu(self):
+        self.mu = np.zeros((self.N, self.K - 1))
+
+    def init_sigma(self):
+        self.sigma = np.zeros(((self.K - 1), (self.K - 1)))
+        np.fill_diagonal(self.sigma, 20)
+
+    def init_eta(self):
+        self.eta = np.zeros((self.N, self.K - 1))
+
+    def init_theta(self):
+        self.theta = np.zeros((self.N, self.K))
+
+    # ------------------------------------------------------------------ E-step (stm.py:489-597)
+    def _preamble(self):
+        """stm.py:497-510 with the reference's own numpy expression (element-wise `*`)."""
+        sigobj = np.linalg.cholesky(self.sigma)  # LinAlgError if Sigma is not PD
+        self.sigmaentropy = np.sum(np.log(np.diag(sigobj)))
+        self.siginv = np.linalg.inv(sigobj).T * np.linalg.inv(sigobj)
+
+    def _estep_device(self):
+        """Run the kernels on the resident state; results stay in HBM."""
+        self._preamble()
+        for name in ("beta", "eta", "mu"):
+            self._push(name)
+        t0 = time.time()
+        bound_local = self._engine.estep(self.siginv, float(self.sigmaentropy))
+        self._fresh["eta"] = "device"
+        self._fresh["theta"] = "device"
+        self._estep_seconds = time.time() - t0
+        return bound_local
+
+    def E_step(self):
+        """Drop-in for STM.E_step: returns (beta_ss, sigma_ss) as numpy arrays."""
+        start_time = time.time()
+        bound_local = self._estep_device()
+        bound, _ = self.comm.allreduce_suffstats(self._engine, np.zeros(0))
+        if self.comm.size == 1:
+            bound = bound_local
+        beta_ss = self._engine.get_beta_ss()
+        sigma_ss = self._engine.get_sigma_ss()
+        try:
+            self.phi = self._engine.get_phi_last()  # stm.py:1116 leaves the last document's phi
+        except Exception:
+            self.phi = None
+        self.bound = bound
+        self.last_bounds.append(self.bound)
+        logger.info(f"Lower Bound: {self.bound}")
+        logger.info(f"Completed E-Step in {np.round(time.time() - start_time, 3)} seconds. \n")
+        return beta_ss, sigma_ss
+
+    def get_beta(self, words, aspect):
+        """stm.py:599-620 (host view; the kernels gather on the device)."""
+        if self.interactions:
+            return self.beta[aspect][:, np.array(np.intp(words))]
+        return self.beta[:, np.array(np.intp(words))]
+
+    def solver_diagnostics(self):
+        """Per-document scipy-style status / nit / nfev / njev and the PD-fix path of the last E-step."""
+        return self._engine.get_diagnostics()
+
+    # ------------------------------------------------------------------ M-step (stm.py:622-747)
+    def M_step(self, beta_ss, sigma_ss):
+        """Host M-step on numpy arrays, mirroring the reference statement by statement."""
+        start_time = time.time()
+        self.update_mu()
+        self.update_sigma(nu=sigma_ss, sigprior=self.sigma_prior)
+        self.update_beta(beta_ss)
+        logger.info(f"Completed M-Step in {np.round(time.time() - start_time, 3)} seconds. \n")
+
+    def _regress(self, prev_cov, eta, intercept=True):
+        if self.mode == "lasso":
+            import sklearn.linear_model
+            return sklearn.linear_model.Lasso(alpha=1, fit_intercept=intercept).fit(prev_cov, eta).coef_
+        if self.mode == "ridge":
+            import sklearn.linear_model
+            return sklearn.linear_model.Ridge(alpha=0.1, fit_intercept=intercept).fit(prev_cov, eta).coef_
+        if self.mode != "ols":
+            print("Need to specify the estimation mode of prevalence covariate coefficients. Uses default 'ols'.")
+        # sklearn LinearRegression(fit_intercept=True): centre, then minimum-norm least squares
+        Xc = prev_cov - prev_cov.mean(axis=0)
+        yc = eta - eta.mean(axis=0)
+        coef, *_ = np.linalg.lstsq(Xc, yc, rcond=max(Xc.shape) * np.finfo(np.float64).eps)
+        return coef.T
+
+    def update_mu(self, intercept=True):
+        if self.comm.size > 1:
+            raise RuntimeError("the host M-step is single-process; sharded fits use expectation_maximization()")
+        if self.model == "CTM":
+            self.mu = np.repeat(np.mean(self.eta, axis=0)[None, :], self.N, axis=0)  # stm.py:651
+        elif self.model == "STM":
+            prev_cov = self._Xenc
+            self.gamma = self._regress(prev_cov, self.eta, intercept)  # stm.py:703: coef_ only
+            self.mu = prev_cov @ self.gamma.T                          # stm.py:704-706: no intercept
+        else:
+            raise ValueError('Updating the topical prevalence parameter requires a mode. Choose from "CTM", '
+                             '"Pooled" or "L1" (default).')
+
+    def update_sigma(self, nu, sigprior=0):
+        assert 0 <= sigprior <= 1, "weight needs to be defined between 0 and 1"
+        diff = self.eta - self.mu
+        covariance = np.array(diff.T @ diff, dtype="float64")
+        self._finish_sigma(covariance, nu, sigprior)
+
+    def _finish_sigma(self, covariance, nu, sigprior):
+        sigma = np.array((covariance + nu) / self.N_total, dtype="float64")  # stm.py:725
+        self.sigma = np.diag(np.diag(sigma)) * sigprior + (1 - sigprior) * sigma  # stm.py:728
+
+    def update_beta(self, beta_ss):
+        if self.LDAbeta:
+            assert np.any(np.sum(beta_ss, axis=1) >= 0), "break here"
+            row_sums = np.sum(beta_ss, axis=1)[:, None]  # 3-D beta_ss: this sums over topics (reference quirk)
+            self.beta = np.divide(beta_ss, row_sums, out=np.zeros_like(beta_ss), where=row_sums != 0)
+        else:
+            raise NotImplementedError("lda_beta=False (mnreg, reference stm.py:749-853) is out of scope")
+
+    # ------------------------------------------------------------------ device-resident EM iteration
+    def _em_iteration_resident(self):
+        """E-step + one all-reduce + M-step with eta / mu / beta / theta kept in HBM.
+
+        Same arithmetic as E_step() + M_step(); the regression and covariance are formed from
+        moments so that document shards only exchange O(K^2 + K V) numbers.
+        """
+        eng = self._engine
+        n = self.K - 1
+        t0 = time.time()
+        bound_local = self._estep_device()
+        t1 = time.time()
+        use_reg = self.model == "STM"
+        if self.model not in ("STM", "CTM"):
+            raise ValueError("model_type must be 'STM' or 'CTM'")
+        if use_reg and self.mode not in ("ols", "ridge"):
+            raise NotImplementedError("mode='lasso' needs the full eta on the host: use E_step()/M_step()")
+        if use_reg and not self._cov_on_device:
+            eng.put_covariates(self._Xenc)
+            self._cov_on_device = True
+        p = self._Xenc.shape[1] if use_reg else 0
+        mom = eng.moments(p)
+        bound, mom = self.comm.allreduce_suffstats(eng, mom)
+        if self.comm.size == 1:
+            bound = bound_local
+        self.bound = bound
+        self.last_bounds.append(self.bound)
+        Ntot = mom[0]
+        sx = mom[1:1 + p]
+        se = mom[1 + p:1 + p + n]
+        if use_reg:
+            XtX = mom[1 + p + n:1 + p + n + p * p].reshape(p, p)
+            Xte = mom[1 + p + n + p * p:].reshape(p, n)
+            xbar, ebar = sx / Ntot, se / Ntot
+            Sxx = XtX - Ntot * np.outer(xbar, xbar)
+            Sxe = Xte - Ntot * np.outer(xbar, ebar)
+            if self.mode == "ridge":
+                coef = np.linalg.solve(Sxx + 0.1 * np.eye(p), Sxe)          # Ridge(alpha=0.1)
+            else:
+                coef = np.linalg.pinv(Sxx, rcond=1e-12, hermitian=True) @ Sxe  # minimum-norm OLS
+            self.gamma = coef.T                                              # (K-1) x p, stm.py:703
+            eng.set_mu_regression(self.gamma)
+        else:
+            eng.set_mu_constant(se / Ntot)                                   # stm.py:651
+        self._fresh["mu"] = "device"
+        cov = self.comm.allreduce_small(eng, eng.covariance())               # stm.py:723
+        sigma_ss = eng.get_sigma_ss()
+        self._finish_sigma(cov, sigma_ss, self.sigma_prior)
+        if not self.LDAbeta:
+            raise NotImplementedError("lda_beta=False (mnreg, reference stm.py:749-853) is out of scope")
+        eng.update_beta()                                                    # stm.py:741-745
+        self._fresh["beta"] = "device"
+        t2 = time.time()
+        self.timings.append(dict(estep=t1 - t0, mstep=t2 - t1, kernels=eng.kernel_ms()))
+
+    # ------------------------------------------------------------------ EM driver (stm.py:855-903)
+    def expectation_maximization(self, saving, output_dir=None, resident=True):
+        first_start_time = time.time()
+        logger.info(f"Fit STM for {self.K} topics")
+        for _iteration in range(100):
+            if resident and not (self.model == "STM" and self.mode == "lasso"):
+                self._em_iteration_resident()
+            else:
+                beta_ss, sigma_ss = self.E_step()
+                self.M_step(beta_ss, sigma_ss)
+            if self.EM_is_converged(_iteration):
+                self.time_processed = time.time() - first_start_time
+                logger.info(f"model converged in iteration {_iteration} after {self.time_processed}s")
+                break
+            if self.max_its_reached(_iteration):
+                self.time_processed = time.time() - first_start_time
+                logger.info(f"maximum number of iterations ({self.max_em_its}) reached after "
+                            f"{self.time_processed} seconds")
+                break
+        if saving:
+            assert output_dir is not None
+            self.save_model(output_dir)
+
+    fit = expectation_maximization  # the name BASELINE.json's north_star uses
+
+    def estep(self):
+        return self.E_step()
+
+    def EM_is_converged(self, _iteration, convergence=None):
+        if _iteration < 1:
+            return False
+        new = self.bound
+        old = self.last_bounds[-2]
+        convergence_check = np.abs((new - old) / np.abs(old))
+        logger.info(f"relative change: {convergence_check}")
+        return bool(convergence_check < self.convergence_threshold)
+
+    def max_its_reached(self, _iteration):
+        return _iteration == self.max_em_its - 1
+
+    def stable_softmax(self, x):
+        xshift = x - np.max(x)
+        exps = np.exp(xshift)
+        return exps / np.sum(exps)
+
+    # ------------------------------------------------------------------ persistence (stm.py:1120-1149)
+    def save_model(self, output_dir):
+        os.makedirs(output_dir, exist_ok=True)
+        np.save(os.path.join(output_dir, "beta_hat"), self.beta)
+        np.save(os.path.join(output_dir, "theta_hat"), self.theta)
+        np.save(os.path.join(output_dir, "sigma_hat"), self.sigma)
+        np.save(os.path.join(output_dir, "eta_hat"), self.eta)
+        np.save(os.path.join(output_dir, "mu_hat"), self.mu)
+        np.save(os.path.join(output_dir, "X"), self.X)
+        if self.model == "STM":
+            np.save(os.path.join(output_dir, "gamma_hat"), self.gamma)
+        with open(os.path.join(output_dir, "lower_bound.pickle"), "wb") as f:
+            pickle.dump(self.last_bounds, f)
+
+    def close(self):
+        if hasattr(self._engine, "close"):
+            self._engine.close()
