@@ -1,0 +1,260 @@
+"""Parity of the HIP E-step (through the C-ABI of include/stm_estep.h) on a real MI355X.
+
+Compared against (i) the CPU oracle on the same inputs, (ii) the golden vectors produced by the
+reference, and (iii) at BASELINE.json's full size (100k documents, V=10k, K=50) size-independent
+properties.  fp64 tolerances: scipy status / nit / PD path exact,
+eta <= 1e-7 abs, per-document bound <= 1e-8 rel, total ELBO <= 1e-9 rel (north_star asks 1e-6).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, reference_beta0
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("toy_ctm", 2), ("edge", 2), ("content_a2", 2), ("c1_k10", 3), ("k50_v10k", 2), ("wiki_k50", 2)]
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def _norm_beta(bss):
+    rs = bss.sum(axis=1)[:, None]
+    return np.divide(bss, rs, out=np.zeros_like(bss), where=rs != 0)
+
+
+def _check(d, o, tag):
+    assert np.array_equal(d["status"], o["status"]), f"{tag}: scipy status differs"
+    assert np.array_equal(d["nit"], o["nit"]), f"{tag}: BFGS iteration counts differ"
+    assert np.array_equal(d["pd_path"], o["pd_path"]), f"{tag}: PD-fix path differs"
+    assert np.max(np.abs(d["eta"] - o["eta"])) <= 1e-7, tag
+    assert np.max(np.abs(d["theta"] - o["theta"])) <= 1e-7, tag
+    assert np.max(np.abs(d["bound_doc"] - o["bound_doc"]) / np.abs(o["bound_doc"])) <= 1e-8, tag
+    assert abs(d["bound"] - o["bound"]) <= 1e-9 * abs(o["bound"]), tag
+    assert _rel(d["sigma_ss"], o["sigma_ss"]) <= 1e-7, tag
+    assert _rel(d["beta_ss"], o["beta_ss"]) <= 1e-7, tag
+
+
+def test_native_library_is_what_runs():
+    from strutopy_amd import _lib
+    from strutopy_amd.engine import HipEstepEngine
+    e = HipEstepEngine(0)
+    info = e.device_info()
+    e.close()
+    assert "gfx950" in info["name"] and info["cu"] >= 200
+    assert any(os.path.basename(_lib.LIB_PATH) in line for line in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("name,its", CASES)
+def test_estep_matches_oracle_and_reference(oracle, name, its):
+    from strutopy_amd.engine import estep_host
+    g = load_golden(name)
+    aspect = g["aspect"] if "aspect" in g.files else None
+    beta = g["beta0"] if "beta0" in g.files else reference_beta0(int(g["K"]), int(g["V"]))
+    for it in range(its):
+        p = f"it{it}_"
+        args = (g["indptr"], g["indices"], g["counts"], beta, g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                float(g[p + "sigmaentropy"]))
+        o = oracle.estep(*args, aspect=aspect, nthreads=0)
+        d = estep_host(*args, aspect=aspect)
+        _check(d, o, f"{name} it{it}")
+        # and directly against what the reference produced
+        assert np.array_equal(d["status"], g[p + "status"]) and np.array_equal(d["nit"], g[p + "nit"])
+        assert np.max(np.abs(d["eta"] - g[p + "eta"])) <= 1e-7
+        assert abs(d["bound"] - float(g[p + "bound"])) <= 1e-9 * abs(float(g[p + "bound"]))
+        assert _rel(d["sigma_ss"], g[p + "sigma_ss"]) <= 1e-7
+        if p + "beta_ss" in g.files:
+            assert _rel(d["beta_ss"], g[p + "beta_ss"]) <= 1e-7
+        else:
+            assert _rel(d["beta_ss"][:, g["sample_cols"]], g[p + "beta_ss_cols"]) <= 1e-7
+            assert _rel(d["beta_ss"].sum(axis=0), g[p + "beta_ss_colsum"]) <= 1e-7
+        beta = g[p + "beta_out"] if p + "beta_out" in g.files else _norm_beta(o["beta_ss"])
+
+
+def test_wiki_known_answer_shipped_by_reference():
+    from strutopy_amd.engine import estep_host
+    g = load_golden("wiki_k50")
+    shipped = float(g["shipped_lower_bound"][0])   # -855111.02, reference_model/50/lower_bound.pickle
+    d = estep_host(g["indptr"], g["indices"], g["counts"], reference_beta0(50, int(g["V"])), g["it0_mu_in"],
+                   g["it0_eta_in"], g["it0_siginv"], float(g["it0_sigmaentropy"]))
+    assert abs(d["bound"] - shipped) <= 1e-9 * abs(shipped)
+
+
+def test_hessian_cholesky_nu_per_document(monkeypatch):
+    from strutopy_amd.engine import HipEstepEngine
+    monkeypatch.setenv("STM_DEBUG_DUMP", "1")
+    for name in ("toy_ctm", "edge"):
+        g = load_golden(name)
+        e = HipEstepEngine(0)
+        e.set_corpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+        e.set_topics(int(g["K"]))
+        e.put_beta(g["beta0"]); e.put_mu(g["it0_mu_in"]); e.put_eta(g["it0_eta_in"])
+        e.estep(g["it0_siginv"], float(g["it0_sigmaentropy"]))
+        hess, chol, nu = e.debug_mats()
+        phi = e.get_phi_last()
+        e.close()
+        assert _rel(hess, g["it0_hess"]) <= 1e-7, name
+        assert _rel(chol, g["it0_chol"]) <= 1e-7, name
+        assert _rel(nu, g["it0_nu"]) <= 1e-6, name
+        assert _rel(phi, g["it0_phi_last"]) <= 1e-7, name
+
+
+@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (64, 90)])
+def test_shapes_at_the_limits(oracle, K, nd_max):
+    """smallest / largest K of this build and documents longer than one 64-word tile."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(K)
+    V, N = 900, 70
+    docs = [np.sort(rng.choice(V, int(rng.integers(1, nd_max + 1)), replace=False)) for _ in range(N)]
+    docs[0] = np.arange(nd_max)
+    indptr = np.concatenate([[0], np.cumsum([len(d) for d in docs])]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 6, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    n = K - 1
+    mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
+    Bm = rng.normal(size=(n, n)); sigma = Bm @ Bm.T + np.eye(n)
+    siginv, sigent = oracle.preamble(sigma)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K}")
+    dense = np.linalg.inv(sigma)          # a caller-supplied dense siginv takes the general path
+    args = (indptr, indices, counts, beta, mu, eta, dense, sigent)
+    _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
+
+
+def test_invalid_inputs_raise_like_the_reference():
+    from strutopy_amd.engine import HipEstepEngine, estep_host
+    g = load_golden("toy_ctm")
+    args = [g["indptr"], g["indices"], g["counts"], g["beta0"].copy(), g["it0_mu_in"], g["it0_eta_in"],
+            g["it0_siginv"], float(g["it0_sigmaentropy"])]
+    args[3][1, int(g["indices"][3])] = -1e-9
+    with pytest.raises(AssertionError):      # "Some entries of beta are negative or nan." stm.py:534
+        estep_host(*args)
+    args[3][1, int(g["indices"][3])] = np.nan
+    with pytest.raises(AssertionError):
+        estep_host(*args)
+    e = HipEstepEngine(0)
+    with pytest.raises(ValueError):          # empty document: the reference indexes doc_array[:, 0]
+        e.set_corpus(np.array([0, 2, 2]), np.array([1, 2]), np.array([1.0, 1.0]), 5)
+    with pytest.raises(ValueError):          # word id outside the dictionary
+        e.set_corpus(np.array([0, 2]), np.array([1, 7]), np.array([1.0, 1.0]), 5)
+    with pytest.raises(ValueError):          # call order
+        e.set_topics(4)
+    e.close()
+
+
+def test_stm_class_reproduces_reference_traces(oracle):
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import PackedCorpus
+    g = load_golden("toy_ctm")
+    c = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+    for resident in (True, False):
+        m = STM(documents=c, dictionary=None, content=False, K=3, X=g["X"][:, 0], kappa_interactions=False,
+                max_em_iter=2, sigma_prior=0, convergence_threshold=1e-5, init_type="random", model_type="CTM")
+        m.expectation_maximization(saving=False, resident=resident)
+        assert m.bound == pytest.approx(float(g["final_bound"]), rel=1e-9)    # tests/test_integration.py pipeline
+        assert np.allclose(m.beta, g["it1_beta_out"], rtol=1e-7, atol=1e-12)
+        assert np.allclose(m.sigma, g["it1_sigma_out"], rtol=1e-7, atol=1e-10)
+        m.close()
+    g = load_golden("c1_k10")
+    c = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+    m = STM(documents=c, dictionary=None, content=False, K=10, X=g["X"][:, 0], kappa_interactions=False,
+            max_em_iter=3, sigma_prior=0, convergence_threshold=1e-12, init_type="random", model_type="STM")
+    beta_ss, sigma_ss = m.E_step()
+    assert np.allclose(beta_ss, g["it0_beta_ss"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(sigma_ss, g["it0_sigma_ss"], rtol=1e-7)
+    assert np.allclose(m.phi, g["it0_phi_last"], rtol=1e-7)
+    m.M_step(beta_ss, sigma_ss)
+    assert np.allclose(m.gamma, g["it0_gamma"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(m.beta, g["it0_beta_out"], rtol=1e-7, atol=1e-14)
+    m.last_bounds = []
+    m.beta = g["beta0"]; m.init_mu(); m.init_eta(); m.init_sigma()
+    m.expectation_maximization(saving=False)            # device-resident E+M iterations
+    for it in range(3):
+        assert m.last_bounds[it] == pytest.approx(float(g[f"it{it}_bound"]), rel=1e-8)
+    assert np.allclose(m.sigma, g["it2_sigma_out"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(m.beta, g["it2_beta_out"], rtol=1e-5, atol=1e-10)
+    assert np.allclose(m.theta.sum(axis=1), 1.0, atol=1e-12)
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    """BASELINE.json configs[1]: 100k synthetic documents x 150 words, V=10k, K=50."""
+    from strutopy_amd.corpus import synthetic_corpus
+    from strutopy_amd.engine import HipEstepEngine
+    syn = synthetic_corpus(100_000, 10_000, 50, n_words=150, seed=12345)
+    c = syn.corpus
+    K, n = 50, 49
+    beta = reference_beta0(K, c.V)
+    e = HipEstepEngine(0)
+    e.set_corpus(c.indptr, c.indices, c.counts, c.V)
+    e.set_topics(K)
+    e.put_beta(beta)
+    siginv, sigent = np.eye(n) / 20.0, float(n * 0.5 * np.log(20.0))
+    bound = e.estep(siginv, sigent)
+    out = dict(corpus=c, beta=beta, siginv=siginv, sigent=sigent, bound=bound, eta=e.get_eta(), theta=e.get_theta(),
+               beta_ss=e.get_beta_ss(), sigma_ss=e.get_sigma_ss(), bound_doc=e.get_bound_docs(),
+               diag=e.get_diagnostics(), engine=e)
+    yield out
+    e.close()
+
+
+def test_full_size_invariants(full_size):
+    f = full_size
+    c = f["corpus"]
+    # phi columns sum to the word count (stm.py:1115-1116)  =>  beta_ss column sums = corpus word totals
+    assert _rel(f["beta_ss"].sum(axis=0), c.word_counts()) <= 1e-11
+    assert abs(f["beta_ss"].sum() - c.counts.sum()) <= 1e-11 * c.counts.sum()
+    assert f["beta_ss"].min() >= 0
+    assert np.allclose(f["theta"].sum(axis=1), 1.0, atol=1e-12) and f["theta"].min() > 0
+    assert np.allclose(f["theta"][:, :-1] / f["theta"][:, -1:], np.exp(f["eta"]), rtol=1e-12)   # softmax([eta, 0])
+    s = f["sigma_ss"]
+    assert np.allclose(s, s.T, rtol=1e-12) and np.linalg.eigvalsh(s).min() > 0                 # sum of H^-1, all PD
+    assert np.isfinite(f["bound_doc"]).all() and f["bound"] == pytest.approx(f["bound_doc"].sum(), rel=1e-12)
+    assert set(np.unique(f["diag"]["status"])) <= {0, 2} and f["diag"]["nit"].max() < 200 * 49
+    assert set(np.unique(f["diag"]["pd_path"])) <= {0, 1, 2}
+
+
+def test_full_size_sample_against_oracle(oracle, full_size):
+    f = full_size
+    S = 3000
+    sub = f["corpus"].slice(0, S)
+    z = np.zeros((S, 49))
+    o = oracle.estep(sub.indptr, sub.indices, sub.counts, f["beta"], z, z, f["siginv"], f["sigent"], nthreads=0)
+    assert np.array_equal(f["diag"]["status"][:S], o["status"]) and np.array_equal(f["diag"]["nit"][:S], o["nit"])
+    assert np.array_equal(f["diag"]["pd_path"][:S], o["pd_path"])
+    assert np.max(np.abs(f["eta"][:S] - o["eta"])) <= 1e-7
+    assert np.max(np.abs(f["bound_doc"][:S] - o["bound_doc"]) / np.abs(o["bound_doc"])) <= 1e-8
+    assert abs(f["bound_doc"][:S].sum() - o["bound"]) <= 1e-9 * abs(o["bound"])
+
+
+def test_full_size_repeatable_and_shard_linear(full_size):
+    """Re-running from the same inputs repeats eta exactly (no cross-document coupling); the
+    sufficient statistics of two document shards add up to the full ones (what the all-reduce relies on)."""
+    from strutopy_amd.engine import HipEstepEngine
+    f = full_size
+    e = f["engine"]
+    e.put_eta(np.zeros_like(f["eta"]))
+    b2 = e.estep(f["siginv"], f["sigent"])
+    assert np.array_equal(e.get_eta(), f["eta"]) and np.array_equal(e.get_bound_docs(), f["bound_doc"])
+    assert b2 == f["bound"]
+    assert _rel(e.get_beta_ss(), f["beta_ss"]) <= 1e-12          # fp64 atomics: order-dependent rounding only
+    c = f["corpus"]
+    half = c.N // 2
+    acc_b, acc_s, acc_bound = np.zeros_like(f["beta_ss"]), np.zeros_like(f["sigma_ss"]), 0.0
+    for lo, hi in ((0, half), (half, c.N)):
+        sh = c.slice(lo, hi)
+        es = HipEstepEngine(0)
+        es.set_corpus(sh.indptr, sh.indices, sh.counts, c.V)
+        es.set_topics(50)
+        es.put_beta(f["beta"])
+        acc_bound += es.estep(f["siginv"], f["sigent"])
+        acc_b += es.get_beta_ss(); acc_s += es.get_sigma_ss()
+        assert np.array_equal(es.get_eta(), f["eta"][lo:hi])
+        es.close()
+    assert _rel(acc_b, f["beta_ss"]) <= 1e-12 and _rel(acc_s, f["sigma_ss"]) <= 1e-12
+    assert acc_bound == pytest.approx(f["bound"], rel=1e-13)

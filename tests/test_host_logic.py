@@ -1,0 +1,221 @@
+"""Host-side logic of strutopy_amd (no GPU): corpus packing, the synthetic generator, the STM
+mirror class' state plumbing / M-step / EM driver -- driven through the `engine=` test hook
+with tests/_oracle_engine.OracleEngine standing in for the HIP engine -- against the golden
+vectors produced by the reference (tools/make_golden.py)."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from _oracle_engine import OracleEngine
+from conftest import ROOT, load_golden
+
+from strutopy_amd.corpus import PackedCorpus, pack_bow, synthetic_corpus
+from strutopy_amd.dist import shard_bounds
+from strutopy_amd.stm import STM, encode_covariates
+
+
+def _corpus(g):
+    return PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+
+
+def _model(g, model_type, max_em_iter, **kw):
+    return STM(documents=_corpus(g), dictionary=None, content=kw.pop("content", False), K=int(g["K"]),
+               X=g["X"][:, 0], kappa_interactions=kw.pop("kappa_interactions", False), max_em_iter=max_em_iter,
+               sigma_prior=0, convergence_threshold=1e-5, init_type="random", model_type=model_type,
+               engine=OracleEngine(), **kw)
+
+
+# ----------------------------------------------------------------------------- corpus
+def test_pack_bow_roundtrip_and_errors():
+    docs = [[(3, 2), (7, 1)], [(0, 5)], [(1, 1), (2, 1), (9, 4)]]
+    c = pack_bow(docs, V=10)
+    assert c.N == 3 and c.nnz == 6 and c.V == 10
+    assert c.indptr.tolist() == [0, 2, 3, 6] and c.indices.dtype == np.int32 and c.counts.dtype == np.float64
+    assert c.to_bow() == docs
+    assert c.word_counts().tolist() == [5, 1, 1, 2, 0, 0, 0, 1, 0, 4]
+    assert pack_bow(c) is c
+    s = c.slice(1, 3)
+    assert s.to_bow() == docs[1:]
+    with pytest.raises(IndexError):   # the reference indexes doc_array[:, 0] (stm.py:523)
+        pack_bow([[(1, 1)], []])
+    with pytest.raises(IndexError):   # beta[:, idx] with idx >= V (stm.py:617)
+        pack_bow([[(11, 1)]], V=10)
+
+
+def test_synthetic_corpus_follows_the_dgp():
+    a = synthetic_corpus(300, 500, 6, n_words=40, seed=5)
+    b = synthetic_corpus(300, 500, 6, n_words=40, seed=5)
+    c = a.corpus
+    assert np.array_equal(c.indices, b.corpus.indices) and np.array_equal(c.counts, b.corpus.counts)
+    assert c.N == 300 and a.X.shape == (300, 1) and set(np.unique(a.X)) <= {0.0, 1.0}
+    per_doc = np.add.reduceat(c.counts, c.indptr[:-1])
+    assert np.all(per_doc == 40)                        # Multinomial(n_words, .), generate_docs.py:302
+    for i in range(c.N):                                 # unique ids within a document
+        ids = c.indices[c.indptr[i]:c.indptr[i + 1]]
+        assert len(np.unique(ids)) == len(ids)
+    assert c.indices.min() == 0 and c.indices.max() == c.V - 1 and c.V <= 500
+    assert len(np.unique(c.indices)) == c.V               # unused terms dropped (generate_docs.py:304-316)
+    assert np.allclose(a.beta_true.sum(axis=1), 1.0)
+    keep = synthetic_corpus(50, 500, 6, n_words=40, seed=5, remove_terms=False)
+    assert keep.corpus.V == 500
+
+
+def test_shard_bounds_cover_and_balance():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 200, size=1000)
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    for world in (1, 2, 3, 8):
+        b = shard_bounds(indptr, world)
+        assert b[0][0] == 0 and b[-1][1] == 1000 and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        nnz = [indptr[hi] - indptr[lo] for lo, hi in b]
+        assert max(nnz) - min(nnz) <= 2 * lens.max()
+
+
+def test_encode_covariates_matches_update_mu_preparation():
+    x = np.array([0, 1, 1, 0])
+    assert np.array_equal(encode_covariates(x), x[:, None].astype(float))       # already 0/1: kept (stm.py:665)
+    cat = np.array([2, 0, 1, 2])
+    enc = encode_covariates(cat)                                                 # one-hot, sorted categories
+    assert np.array_equal(enc, np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]]))
+    assert encode_covariates(None) is None
+
+
+# ----------------------------------------------------------------------------- STM mirror
+def test_constructor_state_matches_reference_init():
+    g = load_golden("toy_ctm")
+    m = _model(g, "CTM", 2)
+    K, V, N = int(g["K"]), int(g["V"]), len(g["indptr"]) - 1
+    assert m.beta.shape == (K, V) and m.theta.shape == (N, K) and m.eta.shape == (N, K - 1)
+    assert m.sigma.shape == (K - 1, K - 1) and np.array_equal(m.sigma, 20 * np.eye(K - 1))   # stm.py:460-461
+    assert np.array_equal(m.beta, g["beta0"])             # legacy-RNG random init, stm.py:361,425-429
+    assert not m.eta.any() and not m.mu.any() and not m.theta.any()
+    assert np.array_equal(m.wcounts, _corpus(g).word_counts())
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_toy_pipeline_reproduces_reference_trace(resident):
+    """The reference's own integration pipeline (tests/test_integration.py:14-68): CTM, 2 EM its."""
+    g = load_golden("toy_ctm")
+    m = _model(g, "CTM", 2)
+    m.expectation_maximization(saving=False, resident=resident)
+    assert len(m.last_bounds) == 2
+    assert m.last_bounds[0] == pytest.approx(float(g["it0_bound"]), rel=1e-10)
+    assert m.bound == pytest.approx(float(g["final_bound"]), rel=1e-9)
+    assert np.allclose(m.mu, g["it1_mu_out"], rtol=0, atol=1e-7)
+    assert np.allclose(m.sigma, g["it1_sigma_out"], rtol=1e-7, atol=1e-10)
+    assert np.allclose(m.beta, g["it1_beta_out"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(m.theta.sum(axis=1), 1.0, atol=1e-4) and np.allclose(m.beta.sum(axis=1), 1.0, atol=1e-4)
+
+
+def test_estep_mstep_surface_one_iteration():
+    """E_step() -> (beta_ss, sigma_ss); M_step(beta_ss, sigma_ss) -- the reference call pattern (stm.py:861-863)."""
+    g = load_golden("c1_k10")
+    m = _model(g, "STM", 3)
+    beta_ss, sigma_ss = m.E_step()
+    assert beta_ss.shape == m.beta.shape and sigma_ss.shape == m.sigma.shape
+    assert m.bound == pytest.approx(float(g["it0_bound"]), rel=1e-10) and m.last_bounds == [m.bound]
+    assert np.allclose(beta_ss, g["it0_beta_ss"], rtol=1e-8, atol=1e-12)
+    assert np.allclose(m.eta, g["it0_eta"], atol=1e-7) and np.allclose(m.theta, g["it0_theta"], atol=1e-7)
+    assert np.allclose(m.phi, g["it0_phi_last"], rtol=1e-8)              # self.phi = last document's phi
+    assert np.allclose(m.siginv, g["it0_siginv"]) and m.sigmaentropy == pytest.approx(float(g["it0_sigmaentropy"]))
+    m.M_step(beta_ss, sigma_ss)
+    assert np.allclose(m.gamma, g["it0_gamma"], rtol=1e-6, atol=1e-9)    # coef_ only, intercept dropped (stm.py:703)
+    assert np.allclose(m.mu, g["it0_mu_out"], atol=1e-8)
+    assert np.allclose(m.sigma, g["it0_sigma_out"], rtol=1e-7, atol=1e-10)
+    assert np.allclose(m.beta, g["it0_beta_out"], rtol=1e-8, atol=1e-14)
+    d = m.solver_diagnostics()
+    assert np.array_equal(d["status"], g["it0_status"]) and np.array_equal(d["nit"], g["it0_nit"])
+
+
+def test_resident_em_three_iterations_stm_ols():
+    g = load_golden("c1_k10")
+    m = _model(g, "STM", 3)
+    m.fit(saving=False)   # north_star's name for expectation_maximization
+    assert len(m.last_bounds) == 3
+    for it in range(3):
+        assert m.last_bounds[it] == pytest.approx(float(g[f"it{it}_bound"]), rel=1e-8)
+    assert np.allclose(m.gamma, g["it2_gamma"], rtol=1e-5, atol=1e-8)
+    assert np.allclose(m.mu, g["it2_mu_out"], atol=1e-7)
+    assert np.allclose(m.sigma, g["it2_sigma_out"], rtol=1e-6, atol=1e-9)
+    # three chained iterations: the 1e-9-level eta differences of A.5 compound into beta
+    assert np.allclose(m.beta, g["it2_beta_out"], rtol=1e-5, atol=1e-10)
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_content_covariate_levels(resident):
+    """kappa_interactions + content: per-level beta (stm.py:430-431,614-615) and the reference's
+    axis=1 normalisation of the 3-D beta_ss (stm.py:741)."""
+    g = load_golden("content_a2")
+    m = _model(g, "STM", 2, content=True, kappa_interactions=True, A=int(g["A"]), beta_index=g["aspect"])
+    assert m.beta.shape == (2, int(g["K"]), int(g["V"])) and np.array_equal(m.beta, g["beta0"])
+    m.expectation_maximization(saving=False, resident=resident)
+    assert m.last_bounds[0] == pytest.approx(float(g["it0_bound"]), rel=1e-10)
+    assert m.last_bounds[1] == pytest.approx(float(g["it1_bound"]), rel=1e-8)
+    assert np.allclose(m.beta, g["it1_beta_out"], rtol=1e-6, atol=1e-12)
+
+
+def test_em_driver_convergence_and_caps():
+    g = load_golden("toy_ctm")
+    m = _model(g, "CTM", 50)
+    m.convergence_threshold = 1.0          # |new-old|/|old| < 1 at the second iteration (stm.py:891-893)
+    m.expectation_maximization(saving=False)
+    assert len(m.last_bounds) == 2
+    assert m.EM_is_converged(0) is False    # needs two bounds (stm.py:885)
+    assert m.max_its_reached(49) and not m.max_its_reached(3)
+
+
+def test_save_model_layout(tmp_path):
+    g = load_golden("c1_k10")
+    m = _model(g, "STM", 1)
+    m.expectation_maximization(saving=True, output_dir=str(tmp_path))
+    for f in ("beta_hat", "theta_hat", "sigma_hat", "eta_hat", "mu_hat", "X", "gamma_hat"):   # stm.py:1123-1141
+        assert os.path.exists(tmp_path / (f + ".npy")), f
+    with open(tmp_path / "lower_bound.pickle", "rb") as fh:
+        assert pickle.load(fh) == m.last_bounds
+    assert np.load(tmp_path / "theta_hat.npy").shape == (m.N, m.K)
+
+
+def test_error_behaviour_matches_reference():
+    g = load_golden("toy_ctm")
+    with pytest.raises(NotImplementedError):
+        STM(documents=_corpus(g), dictionary=None, content=False, K=3, X=g["X"][:, 0], kappa_interactions=False,
+            max_em_iter=1, sigma_prior=0, convergence_threshold=1e-5, init_type="spectral", engine=OracleEngine())
+    with pytest.raises(ValueError):       # stm.py:389-390
+        STM(documents=_corpus(g), dictionary=None, content=False, K=0, X=None, kappa_interactions=False,
+            max_em_iter=1, sigma_prior=0, convergence_threshold=1e-5, init_type="random", engine=OracleEngine())
+    m = _model(g, "CTM", 1)
+    m.sigma = np.array([[1.0, 2.0], [2.0, 1.0]])
+    with pytest.raises(np.linalg.LinAlgError):   # np.linalg.cholesky(self.sigma), stm.py:499
+        m.E_step()
+    m = _model(g, "CTM", 1)
+    b = m.beta.copy(); b[0, int(g["indices"][0])] = -0.5; m.beta = b
+    with pytest.raises(AssertionError):          # stm.py:534
+        m.E_step()
+    with pytest.raises(AssertionError):          # stm.py:720
+        _model(g, "CTM", 1).update_sigma(np.zeros((2, 2)), sigprior=2)
+
+
+def test_accepts_reference_bow_lists_and_dictionary():
+    g = load_golden("toy_ctm")
+    docs = _corpus(g).to_bow()
+    dictionary = {i: str(i) for i in range(int(g["V"]))}
+    m = STM(documents=docs, dictionary=dictionary, content=False, K=3, X=g["X"][:, 0], kappa_interactions=False,
+            max_em_iter=2, sigma_prior=0, convergence_threshold=1e-5, init_type="random", model_type="CTM",
+            engine=OracleEngine())
+    m.expectation_maximization(saving=False)
+    assert m.bound == pytest.approx(float(g["final_bound"]), rel=1e-9)
+
+
+# ----------------------------------------------------------------------------- product hygiene
+def test_product_never_touches_the_oracle():
+    """The shipped package must not import / load anything under oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "strutopy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "libstm_oracle" not in txt and "stm_oracle" not in txt, f

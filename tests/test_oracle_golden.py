@@ -1,0 +1,147 @@
+"""The CPU oracle (oracle/stm_oracle.c) pinned against the golden vectors.
+
+The goldens under tests/golden/ were produced by importing the reference
+(tools/make_golden.py, numpy/scipy versions recorded in every file), so these
+tests are what makes the oracle trustworthy as the checker of the HIP path.
+Tolerances follow SURVEY.md appendix A.5: status / nit / PD path exact,
+eta <= 1e-7 abs, per-document bound <= 1e-9 rel, total ELBO <= 1e-10 rel;
+nfev / njev are informational (the terminal line search runs in rounding noise).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, reference_beta0
+
+CASES = [("toy_ctm", 2), ("edge", 2), ("content_a2", 2), ("c1_k10", 3), ("k50_v10k", 2), ("wiki_k50", 2)]
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def _beta_for(g, it, prev):
+    """beta entering iteration `it`: stored beta0, the reference's seeded random init, or the
+    row-normalised beta_ss of the previous iteration (stm.py:741-745)."""
+    if it == 0:
+        if "beta0" in g.files:
+            return g["beta0"]
+        return reference_beta0(int(g["K"]), int(g["V"]))
+    key = f"it{it - 1}_beta_out"
+    if key in g.files:
+        return g[key]
+    bss = prev["beta_ss"]
+    rs = bss.sum(axis=1)[:, None]
+    return np.divide(bss, rs, out=np.zeros_like(bss), where=rs != 0)
+
+
+@pytest.mark.parametrize("name,its", CASES)
+def test_estep_matches_reference(oracle, name, its):
+    g = load_golden(name)
+    aspect = g["aspect"] if "aspect" in g.files else None
+    prev = None
+    for it in range(its):
+        p = f"it{it}_"
+        beta = _beta_for(g, it, prev)
+        o = oracle.estep(g["indptr"], g["indices"], g["counts"], beta, g[p + "mu_in"], g[p + "eta_in"],
+                         g[p + "siginv"], float(g[p + "sigmaentropy"]), aspect=aspect, nthreads=0)
+        prev = o
+        assert np.array_equal(o["status"], g[p + "status"]), f"{name} it{it}: scipy status differs"
+        assert np.array_equal(o["nit"], g[p + "nit"]), f"{name} it{it}: BFGS iteration counts differ"
+        assert np.array_equal(o["pd_path"], g[p + "pd_path"]), f"{name} it{it}: PD-fix path differs"
+        assert np.max(np.abs(o["eta"] - g[p + "eta"])) <= 1e-7
+        assert np.max(np.abs(o["theta"] - g[p + "theta"])) <= 1e-7
+        assert np.max(np.abs(o["bound_doc"] - g[p + "bound_doc"]) / np.abs(g[p + "bound_doc"])) <= 1e-9
+        assert abs(o["bound"] - float(g[p + "bound"])) <= 1e-10 * abs(float(g[p + "bound"]))
+        assert _rel(o["sigma_ss"], g[p + "sigma_ss"]) <= 1e-8
+        if p + "beta_ss" in g.files:
+            assert _rel(o["beta_ss"], g[p + "beta_ss"]) <= 1e-8
+        else:  # large cases store marginals + a 64-column sample
+            assert _rel(o["beta_ss"].sum(axis=1), g[p + "beta_ss_rowsum"]) <= 1e-9
+            assert _rel(o["beta_ss"].sum(axis=0), g[p + "beta_ss_colsum"]) <= 1e-8
+            assert _rel(o["beta_ss"][:, g["sample_cols"]], g[p + "beta_ss_cols"]) <= 1e-8
+        assert _rel(o["phi_last"], g[p + "phi_last"]) <= 1e-8
+
+
+def test_wiki_known_answer_shipped_by_reference(oracle):
+    """ELBO[0] of src/artifacts/reference_model/50/lower_bound.pickle: the one number the
+    reference itself ships for this path."""
+    g = load_golden("wiki_k50")
+    shipped = float(g["shipped_lower_bound"][0])
+    assert abs(shipped - (-855111.02)) < 0.01
+    beta = reference_beta0(50, int(g["V"]))
+    o = oracle.estep(g["indptr"], g["indices"], g["counts"], beta, g["it0_mu_in"], g["it0_eta_in"],
+                     g["it0_siginv"], float(g["it0_sigmaentropy"]), nthreads=0)
+    assert abs(o["bound"] - shipped) <= 1e-10 * abs(shipped)
+
+
+def test_toy_pipeline_final_bound(oracle):
+    """tests/test_integration.py::_run_toy_pipeline of the reference: final_bound after 2 EM its."""
+    g = load_golden("toy_ctm")
+    assert float(g["final_bound"]) == pytest.approx(-8185.904356877947, rel=1e-14)
+    o = oracle.estep(g["indptr"], g["indices"], g["counts"], g["it0_beta_out"], g["it1_mu_in"], g["it1_eta_in"],
+                     g["it1_siginv"], float(g["it1_sigmaentropy"]))
+    assert abs(o["bound"] - float(g["final_bound"])) <= 1e-10 * abs(float(g["final_bound"]))
+
+
+def test_hessian_cholesky_nu_per_document(oracle):
+    for name in ("toy_ctm", "edge"):
+        g = load_golden(name)
+        o = oracle.estep(g["indptr"], g["indices"], g["counts"], g["beta0"], g["it0_mu_in"], g["it0_eta_in"],
+                         g["it0_siginv"], float(g["it0_sigmaentropy"]), dump_mats=True)
+        assert _rel(o["hess"], g["it0_hess"]) <= 1e-8
+        assert _rel(o["chol"], g["it0_chol"]) <= 1e-8
+        assert _rel(o["nu"], g["it0_nu"]) <= 1e-7
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_objective_gradient_and_bfgs(oracle, dense):
+    """f / df (stm.py:920-958) at random points and scipy BFGS end points, diagonal siginv (what
+    stm.py:501 produces) and a dense one."""
+    g = load_golden("functions")
+    K = int(g["K"])
+    sfx = "_dense" if dense else ""
+    siginv = g["siginv_dense"] if dense else g["siginv"]
+    indptr = g["indptr"]
+    for d in range(len(indptr) - 1):
+        sl = slice(indptr[d], indptr[d + 1])
+        betad = np.ascontiguousarray(g["beta0"][:, g["indices"][sl]])
+        cnt, mu = g["counts"][sl], g["mus"][d]
+        for j in range(4):
+            fv = oracle.f(K, g["etas"][d, j], mu, cnt, betad, siginv)
+            assert abs(fv - g["fvals" + sfx][d, j]) <= 1e-12 * max(1.0, abs(g["fvals" + sfx][d, j]))
+            gv = oracle.df(K, g["etas"][d, j], mu, cnt, betad, siginv)
+            assert np.max(np.abs(gv - g["gvals" + sfx][d, j])) <= 1e-10 * max(1.0, np.max(np.abs(g["gvals" + sfx][d, j])))
+        r = oracle.bfgs(K, g["etas"][d, 1], mu, cnt, betad, siginv)
+        assert r["status"] == int(g["bfgs_status" + sfx][d])
+        assert r["nit"] == int(g["bfgs_nit" + sfx][d])
+        assert np.max(np.abs(r["x"] - g["bfgs_x" + sfx][d])) <= 1e-7
+
+
+def test_make_pd_and_decompose(oracle):
+    g = load_golden("functions")
+    for i, nm in enumerate(g["mat_names"]):
+        M = g["mats"][i]
+        assert np.array_equal(oracle.make_pd(M), g["make_pd"][i]), nm
+        path, L, nu = oracle.decompose(M)
+        assert path >= 0, nm
+        assert _rel(L, g["chol"][i]) <= 1e-12, nm
+        assert _rel(nu, g["nu"][i]) <= 1e-9, nm
+
+
+def test_oracle_rejects_bad_beta(oracle):
+    g = load_golden("toy_ctm")
+    beta = g["beta0"].copy()
+    beta[1, int(g["indices"][0])] = -1e-3
+    with pytest.raises(AssertionError):  # stm.py:534
+        oracle.estep(g["indptr"], g["indices"], g["counts"], beta, g["it0_mu_in"], g["it0_eta_in"],
+                     g["it0_siginv"], float(g["it0_sigmaentropy"]))
+
+
+def test_oracle_thread_count_does_not_change_results(oracle):
+    g = load_golden("edge")
+    args = (g["indptr"], g["indices"], g["counts"], g["beta0"], g["it0_mu_in"], g["it0_eta_in"],
+            g["it0_siginv"], float(g["it0_sigmaentropy"]))
+    a = oracle.estep(*args, nthreads=1)
+    b = oracle.estep(*args, nthreads=0)
+    assert np.array_equal(a["eta"], b["eta"]) and np.array_equal(a["bound_doc"], b["bound_doc"])
+    assert _rel(a["beta_ss"], b["beta_ss"]) <= 1e-13
