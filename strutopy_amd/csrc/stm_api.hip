@@ -77,8 +77,9 @@ struct stm_handle {
     size_t hbm = 0;
     // corpus
     int64_t N = 0, nnz = 0;
-    int V = 0, A = 1, maxNd = 0, NdPad = 64;
+    int V = 0, A = 1, maxNd = 0;
     std::vector<int64_t> h_indptr;
+    std::vector<int32_t> h_len_sorted;   // document lengths in processing order (longest first)
     int64_t *d_indptr = nullptr;
     int32_t *d_indices = nullptr, *d_aspect = nullptr, *d_order = nullptr;
     double *d_counts = nullptr;
@@ -92,7 +93,12 @@ struct stm_handle {
     int *d_counters = nullptr;
     int32_t *d_err = nullptr;
     double *d_slab_beta = nullptr, *d_slab_H = nullptr;
+    size_t slab_beta_len = 0;
     int chunk = 0, nrep = 256;   // documents per launch, replicated nu accumulators
+    // solver launch plan: runs of the longest-first order with equal LDS occupancy
+    struct Group { int64_t first, count; int ld; size_t lds_bytes; bool global; };
+    std::vector<Group> groups;
+    int kreg = 0;                // register-resident topic count of the solver instantiation (0: none)
     // optional dumps
     double *d_phi = nullptr;
     int64_t phi_doc = -1;
@@ -113,6 +119,77 @@ struct stm_handle {
 
 static int use_device(stm_handle *h) {
     HIP_TRY(hipSetDevice(h->device));
+    return STM_OK;
+}
+
+
+using SolverFn = void (*)(stm::SolverParams);
+
+// solver instantiations: KREG topics of the first 64 words in registers (0: none), LDS or global slab
+static SolverFn solver_fn(int kreg, bool global_slab) {
+    if (global_slab) return stm::solver_kernel<1, 0, true>;
+    switch (kreg) {
+    case 16: return stm::solver_kernel<1, 16, false>;
+    case 32: return stm::solver_kernel<1, 32, false>;
+    case 50: return stm::solver_kernel<1, 50, false>;
+    case 64: return stm::solver_kernel<1, 64, false>;
+    default: return stm::solver_kernel<1, 0, false>;
+    }
+}
+
+// slab row length: K rounded up to 4j+2 doubles (see stm_solver.h)
+static int slab_row(int K) { return ((std::max(K, 2) - 2 + 3) / 4) * 4 + 2; }
+
+constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr size_t LDS_STATIC = 2048;   // se / sv / sw of the solver kernel, rounded up
+
+// Cut the longest-first document order into launches of equal LDS occupancy.
+static int plan_solver(stm_handle *h) {
+    const int K = h->K;
+    // STM_SOLVER_MODE: 0 auto (registers + LDS), 1 LDS only, 2 global slab only (v1 data path)
+    const int mode = env_int("STM_SOLVER_MODE", 0);
+    h->kreg = 0;
+    if (mode == 0) h->kreg = K <= 16 ? 16 : K <= 32 ? 32 : K <= 50 ? 50 : 64;
+    const int vreg = h->kreg > 0 ? 64 : 0;
+    const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
+    const int KP = slab_row(K);
+    auto lds_of = [&](int nd) { return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double); };
+    auto per_cu = [&](int nd) -> int {
+        const size_t b = ((lds_of(nd) + LDS_STATIC + 511) / 512) * 512;
+        if (mode == 2 || b > LDS_PER_CU) return 0;
+        return (int)std::min<size_t>((size_t)cmax, LDS_PER_CU / b);
+    };
+    h->groups.clear();
+    size_t max_dyn = 0, glob_len = 0;
+    const int64_t N = h->N;
+    const size_t budget = (size_t)env_int("STM_SLAB_BUDGET_MB", 24576) << 20;
+    for (int64_t i = 0; i < N;) {
+        const int nd = h->h_len_sorted[(size_t)i];
+        const int c = per_cu(nd);
+        int64_t j = i + 1;
+        while (j < N && per_cu(h->h_len_sorted[(size_t)j]) == c) ++j;
+        stm_handle::Group g{i, j - i, 0, 0, c == 0};
+        if (c == 0) {
+            g.ld = (nd + 63) / 64 * 64;
+            const size_t per_doc = (size_t)(KP + 2) * g.ld;
+            const size_t docs = std::min<size_t>((size_t)(j - i), std::max<size_t>(1, budget / (per_doc * sizeof(double))));
+            glob_len = std::max(glob_len, docs * per_doc);
+        } else {
+            g.ld = std::max(0, nd - vreg);
+            g.lds_bytes = lds_of(nd);
+            max_dyn = std::max(max_dyn, g.lds_bytes);
+        }
+        h->groups.push_back(g);
+        i = j;
+    }
+    if (max_dyn > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn);
+        if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+    }
+    h->slab_beta_len = glob_len;
+    dfree(h->d_slab_beta);
+    if (glob_len) if (int rc = dalloc(&h->d_slab_beta, glob_len)) return rc;
     return STM_OK;
 }
 
@@ -193,7 +270,6 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
         for (int64_t i = 0; i < N; ++i)
             if (aspect[i] < 0 || aspect[i] >= A) return fail(STM_ERR_INVALID, "stm_set_corpus: aspect out of range");
     h->N = N; h->V = V; h->A = A; h->nnz = nnz; h->maxNd = maxNd;
-    h->NdPad = std::max(64, (maxNd + 63) / 64 * 64);
     h->h_indptr.assign(indptr, indptr + N + 1);
     if (int rc = dalloc(&h->d_indptr, (size_t)N + 1)) return rc;
     if (int rc = dalloc(&h->d_indices, (size_t)nnz)) return rc;
@@ -216,6 +292,8 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
         return (indptr[a + 1] - indptr[a]) > (indptr[b + 1] - indptr[b]);
     });
     if (N) HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    h->h_len_sorted.resize((size_t)N);
+    for (int64_t i = 0; i < N; ++i) h->h_len_sorted[(size_t)i] = (int32_t)(indptr[order[i] + 1] - indptr[order[i]]);
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->K = 0;
     return STM_OK;
@@ -248,13 +326,12 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = dalloc(&h->d_pd, N)) return rc;
     if (int rc = dalloc(&h->d_counters, 8)) return rc;
     if (int rc = dalloc(&h->d_err, 1)) return rc;
-    // one block (one wave) per document; documents are launched in chunks so the private
-    // slabs (beta_d columns + BFGS H) stay within a fixed HBM budget
-    const size_t slab_bytes = ((size_t)(K + 2) * h->NdPad + n * n) * sizeof(double);
+    // one block (one wave) per document.  The solver keeps beta_d on chip (64 words in registers,
+    // the rest in LDS); launches are cut so every launch has one LDS size / occupancy class.
+    if (int rc = plan_solver(h)) return rc;
     const size_t budget = (size_t)env_int("STM_SLAB_BUDGET_MB", 24576) << 20;
-    h->chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(h->N, 1), (int64_t)(budget / slab_bytes)));
+    h->chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(h->N, 1), (int64_t)(budget / std::max<size_t>(n * n * sizeof(double), 8))));
     h->nrep = env_int("STM_SIGMA_REPLICAS", 256);
-    if (int rc = dalloc(&h->d_slab_beta, (size_t)h->chunk * (size_t)(K + 2) * h->NdPad)) return rc;
     if (int rc = dalloc(&h->d_slab_H, (size_t)h->chunk * n * n)) return rc;
     if (int rc = dalloc(&h->d_sigma_part, (size_t)h->nrep * n * n)) return rc;
     HIP_TRY(hipMemsetAsync(h->d_eta, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));
@@ -373,7 +450,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     }
 
     stm::SolverParams sp{};
-    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.NdPad = h->NdPad;
+    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = slab_row(K);
     sp.indptr = h->d_indptr; sp.indices = h->d_indices; sp.counts = h->d_counts; sp.aspect = h->d_aspect;
     sp.betaT = h->d_betaT; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag;
     sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
@@ -394,11 +471,18 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
-        for (int64_t first = 0; first < h->N; first += h->chunk) {
-            sp.first = first;
-            const unsigned g = (unsigned)std::min<int64_t>(h->chunk, h->N - first);
-            hipLaunchKernelGGL(stm::solver_kernel<1>, dim3(g), dim3(64), 0, h->stream, sp);
-            HIP_TRY(hipGetLastError());
+        for (const auto &gr : h->groups) {
+            const SolverFn fn = gr.global ? solver_fn(0, true) : solver_fn(h->kreg, false);
+            sp.ld = gr.ld;
+            int64_t step = h->chunk;
+            if (gr.global)
+                step = std::min<int64_t>(step, std::max<int64_t>(1, (int64_t)(h->slab_beta_len / ((size_t)(sp.KP + 2) * (size_t)std::max(gr.ld, 1)))));
+            for (int64_t off = 0; off < gr.count; off += step) {
+                sp.first = gr.first + off;
+                const unsigned g = (unsigned)std::min<int64_t>(step, gr.count - off);
+                hipLaunchKernelGGL(fn, dim3(g), dim3(64), gr.lds_bytes, h->stream, sp);
+                HIP_TRY(hipGetLastError());
+            }
         }
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     if (dbg_stage & 2)

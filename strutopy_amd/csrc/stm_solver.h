@@ -7,12 +7,20 @@
 // flow restated as ONE wave-uniform state machine with a single
 // evaluation site, so the K x Nd contraction is instantiated once.
 //
-// Data layout (HBM): beta is held word-major, betaT[A][V][K], so a word's K-vector is one
-// contiguous 8K-byte run; the document's columns are gathered once into a private,
-// L2-resident slab slab[k][NdPad] (v contiguous => every objective evaluation streams it
-// with fully coalesced 512-byte wave loads).  The BFGS inverse-Hessian estimate lives in
-// a second private slab (n x n, touched only nit times).  Lane i holds component i of
-// every length-(K-1) vector; all line-search scalars are wave-uniform.
+// Data layout: beta is held word-major in HBM, betaT[A][V][K], so a word's K-vector is one
+// contiguous 8K-byte run.  The document's K x Nd block beta_d is gathered ONCE and then stays
+// on chip for the ~64 objective evaluations of the solve (re-streaming it from L2/HBM per
+// evaluation was the v1 bottleneck: 0.5 TB of slab traffic per E-step at 100k documents):
+//   * words 0..63   -> registers of the lane that owns the word (breg[KREG], KREG >= K)
+//   * words 64..Nd-1 -> a private LDS slab slab[word][KP], KP = K rounded up to 4j+2: a lane
+//     streams its word's row with ds_read_b128 at immediate offsets, and the row stride of
+//     8j+4 dwords makes every 16-lane group of a wave hit 16 distinct 4-bank slots (no
+//     conflicts); sized per launch from the longest document of the launch -- documents are
+//     launched longest-first in groups of equal LDS occupancy (see stm_api.hip)
+//   * documents too long for the 160 KiB LDS use the GLOBAL_SLAB variant (slab in HBM/L2).
+// exp(eta~ - m) is broadcast through a 64-entry LDS vector.  The BFGS inverse-Hessian
+// estimate lives in a private global slab (n x n, touched only nit times).  Lane i holds
+// component i of every length-(K-1) vector; all line-search scalars are wave-uniform.
 #pragma once
 #include "stm_wave.h"
 
@@ -20,7 +28,7 @@ namespace stm {
 
 struct SolverParams {
     int64_t N;
-    int K, n, V, NdPad;
+    int K, n, V;
     const int64_t *indptr;
     const int32_t *indices;
     const double *counts;
@@ -30,8 +38,10 @@ struct SolverParams {
     double *eta;            // [N][n] in/out
     const double *siginv;   // [n][n]
     int siginv_diag;        // 1: off-diagonals are exactly zero (what stm.py:501 produces)
-    double *slab_beta;      // [grid][(K+2)][NdPad]
+    double *slab_beta;      // GLOBAL_SLAB variant only: [grid][(K+2)][ld]
     double *slab_H;         // [grid][n][n]
+    int ld;                 // slab capacity in words (held outside registers), per launch
+    int KP;                 // slab row length: K rounded up to 4j+2 (16-byte rows, conflict-free ds_read_b128)
     int64_t first;          // this launch covers order[first .. first + gridDim.x)
     const int32_t *order;   // optional processing order (nullable)
     int32_t *status, *nit, *nfev, *njev;
@@ -158,17 +168,21 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
     return true;
 }
 
-template <int VPL>
-__global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
+template <int VPL, int KREG, bool GLOBAL_SLAB>
+__global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
     constexpr int KMAX = 64 * VPL;
-    __shared__ double se[KMAX + 1];  // exp(eta~ - m), broadcast to every lane
+    constexpr int VREG = (KREG > 0) ? WAVE : 0;      // words held in registers
+    constexpr int KR = (KREG > 0) ? KREG : 2;
+    static_assert(KREG % 2 == 0 && KREG <= KMAX, "KREG must be even and <= 64*VPL");
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld]
+    __shared__ __attribute__((aligned(16))) double se[KMAX + 2];  // exp(eta~ - m), broadcast to every lane
     __shared__ double sv[KMAX + 1];  // vector broadcast (matvec operand / s)
     __shared__ double sw[KMAX + 1];  // vector broadcast (w = H y)
     const int lane = threadIdx.x;
-    const int K = P.K, n = P.n, NdPad = P.NdPad;
-    double *slab = P.slab_beta + (size_t)blockIdx.x * (size_t)(K + 2) * NdPad;
-    double *crow = slab + (size_t)K * NdPad;        // counts
-    double *wrow = slab + (size_t)(K + 1) * NdPad;  // counts / colsum(beta_d)
+    const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
+    double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
+    double *crow = slab + (size_t)KP * ld;  // counts of the slab words
+    double *wrow = crow + ld;               // counts / colsum(beta_d)
     double *Hs = P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
     const double *S = P.siginv;
     const bool sdiag = P.siginv_diag != 0;
@@ -181,41 +195,58 @@ __global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
         const int Nd = (int)(P.indptr[doc + 1] - p0);
-        const int npass = (Nd + WAVE - 1) / WAVE;
+        const int NdL = Nd > VREG ? Nd - VREG : 0;  // words in the slab (<= ld)
         const int asp = P.aspect ? P.aspect[doc] : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
 
-        // ---- gather beta_d (stm.py:614-617) into the slab; assert beta >= 0 (stm.py:534)
+        // ---- gather beta_d (stm.py:614-617), lane = word; assert beta >= 0 (stm.py:534)
         double csum = 0.0;
         bool bad = false;
-        for (int pass = 0; pass < npass; ++pass) {
-            const int v = pass * WAVE + lane;
-            if (v < Nd) {
-                const int idx = P.indices[p0 + v];
-                const double c = P.counts[p0 + v];
-                const double *row = bT + (size_t)idx * K;
-                double colsum = 0.0;
-                for (int k = 0; k < K; ++k) {
-                    const double b = row[k];
-                    bad |= !(b >= 0.0);
-                    slab[(size_t)k * NdPad + v] = b;
-                    colsum += b;
-                }
-                crow[v] = c;
-                wrow[v] = c / colsum;
-                csum += c;
-            } else {
-                for (int k = 0; k < K; ++k) slab[(size_t)k * NdPad + v] = 0.0;
-                crow[v] = 0.0;
-                wrow[v] = 0.0;
+        double breg[KR];   // beta_d[:, lane] of word `lane` (KREG > 0)
+        double c0 = 0.0, w0 = 0.0;
+        if (KREG > 0) {
+            const bool act = lane < Nd;
+            const int idx = act ? P.indices[p0 + lane] : 0;
+            const double *row = bT + (size_t)idx * K;
+            double colsum = 0.0;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const double b = (act && k < K) ? row[k] : 0.0;
+                bad |= !(b >= 0.0);
+                breg[k] = b;
+                colsum += b;
+            }
+            if (act) {
+                c0 = P.counts[p0 + lane];
+                w0 = c0 / colsum;
+                csum += c0;
             }
         }
+        for (int vv = lane; vv < NdL; vv += WAVE) {
+            const int idx = P.indices[p0 + VREG + vv];
+            const double c = P.counts[p0 + VREG + vv];
+            const double *row = bT + (size_t)idx * K;
+            double *dst = slab + (size_t)vv * KP;
+            double colsum = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double b = row[k];
+                bad |= !(b >= 0.0);
+                dst[k] = b;
+                colsum += b;
+            }
+            for (int k = K; k < KP; ++k) dst[k] = 0.0;
+            crow[vv] = c;
+            wrow[vv] = c / colsum;
+            csum += c;
+        }
+        // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
+        for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
         __syncthreads();  // slab stores -> visible to the whole wave
         if (wave_any(bad)) {
             atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
             return;
         }
-        const double Ndoc = (double)(long long)wave_sum(csum);  // int(np.sum(word_count)), stm.py:933
+        const ud Ndoc = (double)(long long)wave_sum(csum);  // int(np.sum(word_count)), stm.py:933
 
         // ---- lane vectors
         double x[VPL], g[VPL], p[VPL], xt[VPL], gv[VPL], mu[VPL], sd[VPL], g0[VPL];
@@ -229,16 +260,22 @@ __global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
             g[r] = 0.0; p[r] = 0.0; xt[r] = 0.0; gv[r] = 0.0; g0[r] = 0.0;
         }
         // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
-        for (int k = 0; k < n; ++k) {
+        auto g0_slab = [&](int k) -> double {
             double t = 0.0;
-            for (int pass = 0; pass < npass; ++pass) {
-                const int v = pass * WAVE + lane;
-                t += slab[(size_t)k * NdPad + v] * wrow[v];
-            }
-            t = wave_sum(t);
+            for (int vv = lane; vv < NdL; vv += WAVE) t += slab[(size_t)vv * KP + k] * wrow[vv];
+            return t;
+        };
+        auto g0_put = [&](int k, double t) {
 #pragma unroll
             for (int r = 0; r < VPL; ++r)
                 if (k == lane + WAVE * r) g0[r] = t;
+        };
+        if (KREG > 0) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k)
+                if (k < n) g0_put(k, wave_sum(breg[k] * w0 + g0_slab(k)));
+        } else {
+            for (int k = 0; k < n; ++k) g0_put(k, wave_sum(g0_slab(k)));
         }
 
         int nfev = 0, njev = 0;
@@ -250,30 +287,78 @@ __global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
             for (int r = 0; r < VPL; ++r)
                 if (lane + WAVE * r < n) mloc = nanmax(mloc, xt[r]);
             const double m = wave_nanmax(mloc);
-            double cnt = 0.0, ssum = 0.0;
+            int icnt = 0;
+            double ssum = 0.0;
 #pragma unroll
             for (int r = 0; r < VPL; ++r) {
                 const int i = lane + WAVE * r;
-                if (i < K) {
-                    const double val = (i < n) ? xt[r] : 0.0;
-                    const double e = exp(val - m);
-                    se[i] = e;
-                    if (val == m) cnt += 1.0;
-                    else ssum += e;
-                }
+                const double val = (i < n) ? xt[r] : 0.0;
+                const double e = exp(val - m);
+                if (i < K) se[i] = e;
+                const bool ismax = (i < K) && (val == m);
+                icnt += __popcll(__ballot(ismax));
+                ssum += (i < K && !ismax) ? e : 0.0;
             }
             __syncthreads();
-            cnt = wave_sum(cnt);
             ssum = wave_sum(ssum);
-            // scipy.special.logsumexp: log1p(s/m) + log(m) + a_max
-            const double lse = log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
+            // scipy.special.logsumexp: log1p(s/m) + log(m) + a_max (m = multiplicity of the maximum)
+            double lse;
+            if (icnt == 1) {
+                lse = log1p_pos(ssum) + m;          // s/1, + log(1)
+            } else {
+                const double cnt = (double)icnt;
+                lse = log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
+            }
             double part = 0.0;
-            for (int pass = 0; pass < npass; ++pass) {
-                const int v = pass * WAVE + lane;
-                const double *col = slab + v;
-                double s = 0.0;
-                for (int k = 0; k < K; ++k) s = fma(se[k], col[(size_t)k * NdPad], s);
-                if (v < Nd) part += crow[v] * (m + log(s));
+            const double2 *se2 = reinterpret_cast<const double2 *>(se);
+            if (KREG > 0) {  // words 0..63: beta_d column in registers, two FMA chains
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < KR; k += 2) {
+                    // bound the number of se values in flight (the scheduler would otherwise
+                    // hoist all KREG broadcast reads and spill beta_d out of the VGPRs)
+                    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+                    const double2 e = se2[k / 2];
+                    s0 = fma(e.x, breg[k], s0);
+                    s1 = fma(e.y, breg[k + 1], s1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double lg = m + log_pos(s0 + s1);
+                part = (lane < Nd) ? c0 * lg : 0.0;
+            }
+            // slab words: every lane streams its word's row (ds_read_b128), two 64-word tiles per
+            // sweep so the broadcast se pair is read once for both
+            const int kp2 = KP >> 1;
+            for (int vb = 0; vb < NdL; vb += 2 * WAVE) {
+                const int va = vb + lane, vc = va + WAVE;
+                const bool two = vb + WAVE < NdL;  // uniform
+                const int ia = va < NdL ? va : NdL - 1, ic = vc < NdL ? vc : NdL - 1;
+                const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                const double2 *rc = reinterpret_cast<const double2 *>(slab + (size_t)ic * KP);
+                double a0 = 0.0, a1 = 0.0;
+                if (two) {
+                    double c0s = 0.0, c1s = 0.0;
+#pragma unroll 5
+                    for (int kk = 0; kk < kp2; ++kk) {
+                        const double2 e = se2[kk], ba = ra[kk], bc = rc[kk];
+                        a0 = fma(e.x, ba.x, a0);
+                        a1 = fma(e.y, ba.y, a1);
+                        c0s = fma(e.x, bc.x, c0s);
+                        c1s = fma(e.y, bc.y, c1s);
+                    }
+                    const double la = m + log_pos(a0 + a1), lc = m + log_pos(c0s + c1s);
+                    part += (va < NdL) ? crow[ia] * la : 0.0;
+                    part += (vc < NdL) ? crow[ic] * lc : 0.0;
+                } else {
+#pragma unroll 5
+                    for (int kk = 0; kk < kp2; ++kk) {
+                        const double2 e = se2[kk], ba = ra[kk];
+                        a0 = fma(e.x, ba.x, a0);
+                        a1 = fma(e.y, ba.y, a1);
+                    }
+                    const double la = m + log_pos(a0 + a1);
+                    part += (va < NdL) ? crow[ia] * la : 0.0;
+                }
             }
             part = wave_sum(part);
             double q = 0.0;
@@ -368,26 +453,24 @@ __global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
         // ---- scipy _minimize_bfgs state (optimize/_optimize.py:1328-1502)
         const double gtol = 1e-5, c1 = 1e-4, c2 = 0.9, amax = 1e100, amin = 1e-100, xtol = 1e-14;
         const int maxiter = n * 200;
-        double old_fval = 0, old_old_fval = 0, gnorm = 0;
+        ud old_fval, old_old_fval, gnorm;
         int k = 0, status = 0;
         bool H_ident = true;
         // line-search shared
-        double phi0 = 0, old_phi0 = 0, derphi0 = 0;
+        ud phi0, old_phi0, derphi0;
         // DCSRCH state (optimize/_dcsrch.py)
-        double stx = 0, fx = 0, gx = 0, sty = 0, fy = 0, gy = 0, stmin = 0, stmax = 0, width = 0,
-               width1 = 0, finit = 0, ginit = 0, gtest = 0;
+        ud stx, fx, gx, sty, fy, gy, stmin, stmax, width, width1, finit, ginit, gtest;
         int stage = 1, w1_calls = 0;
         bool brackt = false;
         // wolfe2 / zoom state (optimize/_linesearch.py)
-        double alpha0 = 0, alpha1 = 0, phi_a0 = 0, phi_a1 = 0, derphi_a0 = 0;
+        ud alpha0, alpha1, phi_a0, phi_a1, derphi_a0;
         int w2_i = 0;
-        double a_lo = 0, a_hi = 0, phi_lo = 0, phi_hi = 0, derphi_lo = 0, phi_rec = 0, a_rec = 0,
-               a_j = 0;
+        ud a_lo, a_hi, phi_lo, phi_hi, derphi_lo, phi_rec, a_rec, a_j;
         int zi = 0;
-        double acc_alpha = 0, acc_f = 0;
+        ud acc_alpha, acc_f;
         bool acc_have_g = false;
         // evaluation request / result + scipy ScalarFunction's last-x cache
-        double alpha = 0.0, fval = 0, dval = 0, cache_f = 0;
+        ud alpha, fval, dval, cache_f;
         bool want_eval = true, need_f = true, need_g = true;
         bool have_x = false, f_ok = false, g_ok = false;
         int st = S_INIT_DONE;
@@ -487,7 +570,9 @@ __global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
                         fm = f - stp * gtest; fxm = fx - stx * gtest; fym = fy - sty * gtest;
                         gm = gd - gtest; gxm = gx - gtest; gym = gy - gtest;
                     }
-                    dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
+                    double l_stx = stx, l_sty = sty;
+                    dcstep(l_stx, fxm, gxm, l_sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
+                    stx = l_stx; sty = l_sty;
                     if (mod) {
                         fx = fxm + stx * gtest; fy = fym + sty * gtest;
                         gx = gxm + gtest; gy = gym + gtest;
@@ -571,17 +656,18 @@ __global__ __launch_bounds__(64) void solver_kernel(SolverParams P) {
                 const double dalpha = a_hi - a_lo;
                 double a, b;
                 if (dalpha < 0) { a = a_hi; b = a_lo; } else { a = a_lo; b = a_hi; }
-                double cchk = 0;
+                double cchk = 0, aj = a_j;
                 bool have = false;
                 if (zi > 0) {
                     cchk = 0.2 * dalpha;
-                    have = cubicmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, a_rec, phi_rec, a_j);
+                    have = cubicmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, a_rec, phi_rec, aj);
                 }
-                if (zi == 0 || !have || a_j > b - cchk || a_j < a + cchk) {
+                if (zi == 0 || !have || aj > b - cchk || aj < a + cchk) {
                     const double qchk = 0.1 * dalpha;
-                    have = quadmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, a_j);
-                    if (!have || a_j > b - qchk || a_j < a + qchk) a_j = a_lo + 0.5 * dalpha;
+                    have = quadmin(a_lo, phi_lo, derphi_lo, a_hi, phi_hi, aj);
+                    if (!have || aj > b - qchk || aj < a + qchk) aj = a_lo + 0.5 * dalpha;
                 }
+                a_j = aj;
                 alpha = a_j; need_f = true; need_g = false; want_eval = true;
                 st = S_ZOOM_GOT_F;
             } break;
