@@ -43,6 +43,7 @@ struct PostParams {
     int32_t *pd_path;
     int32_t *err_flag;
     double *hess_out, *chol_out, *nu_out;  // optional [N][n][n] dumps (nullable)
+    int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
 };
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
                     bcol[(size_t)k * MLD] = a * sq / Ssum;   // hessian b, stm.py:1001
                     const double phi = a * w * sq;  // stm.py:1115-1116
                     bad |= !(phi >= 0.0);
-                    unsafeAtomicAdd(bss + k, phi);  // beta_ss[:, idx] += phi, stm.py:588
+                    if (!(P.debug_flags & 1)) unsafeAtomicAdd(bss + k, phi);  // beta_ss[:, idx] += phi, stm.py:588
                     if (P.phi_out && doc == P.phi_doc) P.phi_out[(size_t)k * Nd + v] = phi;
                 }
                 ssq[lane] = sq;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
             if (isk)
                 for (int vv = 0; vv < WAVE; ++vv) rowc += bt[(size_t)lane * MLD + vv] * ssq[vv];
             // b b^T, 8x8 register block per lane
+            if (!(P.debug_flags & 2))
             for (int vv = 0; vv < WAVE; ++vv) {
                 const double *rp = bt + (size_t)(8 * br) * MLD + vv;
                 const double *cp = bt + (size_t)(8 * bc) * MLD + vv;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
         };
         int path = 0;
         bool upper = false, fail = false;
-        bool ok = cholesky();                 // PD test of hessian(), stm.py:1017 (as Cholesky success)
+        bool ok = (P.debug_flags & 8) ? true : cholesky();                 // PD test of hessian(), stm.py:1017 (as Cholesky success)
         if (!ok) {
             make_pd(); path = 1;              // stm.py:1019
             ok = cholesky();                  // stm.py:1020
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
 
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066), accumulated into sigma_ss
         const double Rdiag = 1.0 / Ldiag;
+        if (P.debug_flags & 4) return;
         if (!upper) {
             // R = U^{-1}, U = L^T: column c in lane c, rows from the bottom up; R overwrites the upper triangle
             for (int i = n - 2; i >= 0; --i) {
