@@ -486,13 +486,23 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
             }
         }
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    if (dbg_stage & 2)
-        for (int64_t first = 0; first < h->N; first += h->chunk) {
-            pp.first = first;
-            const unsigned g = (unsigned)std::min<int64_t>(h->chunk, h->N - first);
-            hipLaunchKernelGGL(stm::post_kernel, dim3(g), dim3(64), 0, h->stream, pp);
-            HIP_TRY(hipGetLastError());
-        }
+    if ((dbg_stage & 2) && h->N > 0) {
+        // persistent single-wave workgroups: as many as the LDS / register budget keeps resident
+        using PostFn = void (*)(stm::PostParams);
+        const int nb = (K + 15) / 16;
+        const PostFn pf = nb <= 1 ? stm::post_kernel<1> : nb == 2 ? stm::post_kernel<2>
+                        : nb == 3 ? stm::post_kernel<3> : stm::post_kernel<4>;
+        pp.MLD = n | 1;
+        const size_t lds = stm::post_lds_doubles(n, pp.MLD) * sizeof(double);
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pf, 64, lds));
+        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 8)));
+        const int64_t grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
+        pp.first = 0; pp.count = h->N;
+        hipLaunchKernelGGL(pf, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream,
                        h->d_sigma_part, h->nrep, n * n, h->d_sigma_ss);

@@ -1,20 +1,26 @@
-// stm_post.h -- per-document theta / Hessian / Cholesky / nu / bound / phi: one wavefront per doc.
+// stm_post.h -- per-document theta / Hessian / Cholesky / nu / bound / phi after the solve.
 //
 // Replaces, per document, reference src/modules/stm.py:547-588:
 //   theta (547-549), hessian (986-1026, incl. make_pd 964-984 and the +1e-5 branch),
 //   decompose_hessian (1031-1050), lower_bound (1068-1101), optimize_nu (1052-1066),
 //   update_z (1103-1118) and the sigma_ss / beta_ss accumulation (582-588).
 //
-// Layout: words of the document are processed in tiles of 64 (lane = word): the lane reads
-// its word's contiguous K-vector from betaT[A][V][K], forms b = a*sqrt(c)/colsum(a) and
-// phi, scatters phi into beta_ss (word-major, fp64 HW atomics) and parks b in an LDS tile
-// bt[64 topics][65] (word contiguous: conflict-free writes; the odd leading dimension keeps
-// the strided block reads at <= 2-way).  The K x K contraction b b^T is then accumulated
-// from LDS with an 8x8 register block per lane (lane grid 8x8 -> 64x64 outputs), so each
-// LDS value feeds 8 FMAs.  The (K-1)^2 matrix then lives in ONE padded LDS array (leading dimension 65 =>
-// row- and column-wise lane access are both bank-conflict-free): Cholesky overwrites the
-// strict lower triangle with L, the untouched upper triangle still holds A for the
-// make_pd fallbacks, and U^{-1} later overwrites the upper triangle.
+// One wavefront per workgroup, PERSISTENT over a strided set of documents.  Per document the
+// words are processed in tiles of 16:
+//   1. gather   lane = topic: the tile's 16 beta rows are read from betaT[A][V][K] as 16
+//               coalesced 8K-byte runs and transposed into the LDS tile T[topic][word]
+//   2. reduce   lane = (word, quarter of the topics): colsum S_w and theta.(beta*exp(eta)) per
+//               word, two cross-lane steps; log / sqrt / reciprocal once per word
+//   3. scatter  lane = topic: phi = a*c/S is atomically added to beta_ssT[word][:] -- again one
+//               coalesced 8K-byte run per word (fp64 hardware atomics) -- and T is overwritten
+//               with b = a*sqrt(c)/S
+//   4. b b^T    fp64 MFMA (v_mfma_f64_16x16x4_f64): the K x K contraction, upper block triangle
+//               only, accumulated in registers over all tiles of the document
+// The (K-1)^2 matrix then lives in one LDS array M (aliasing T): Cholesky overwrites the strict
+// lower triangle with L, the untouched upper triangle still holds A for the make_pd fallbacks,
+// and R = L^-T later overwrites the upper triangle.  nu = R R^T = H^-1 is again a Gram product
+// and is accumulated ON THE MATRIX CORES ACROSS ALL DOCUMENTS of the workgroup
+// (sigma_ss = sum_d R_d R_d^T); one atomic flush per workgroup at the end of the launch.
 #pragma once
 #include "stm_wave.h"
 
@@ -38,7 +44,8 @@ struct PostParams {
     double *beta_ssT;      // [A][V][K], pre-zeroed, atomically accumulated
     double *sigma_part;    // [nrep][n][n] replicated accumulators of nu (pre-zeroed, atomics)
     int nrep;
-    int64_t first;         // this launch covers order[first .. first + gridDim.x)
+    int64_t first;         // this launch covers order[first .. first + count)
+    int64_t count;
     const int32_t *order;
     int32_t *pd_path;
     int32_t *err_flag;
@@ -46,39 +53,59 @@ struct PostParams {
     int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
+    int MLD;               // leading dimension of the LDS matrix (odd, >= n)
 };
 
-constexpr int PT = 64;        // topics padded to 64 (K <= 64 in this kernel)
-constexpr int MLD = 65;       // leading dimension of the LDS matrix
+constexpr int PT = 64;    // topics padded to 64 (K <= 64 in this kernel)
+constexpr int TW = 16;    // words per tile
+constexpr int TLD = 18;   // leading dimension of T: MFMA fragment reads are conflict-free
 
-__global__ __launch_bounds__(64) void post_kernel(PostParams P) {
-    // bt tile [PT][MLD] and the n x n matrix [64][MLD] share one LDS region (33 KiB)
-    __shared__ __attribute__((aligned(16))) double smem[64 * MLD];
-    __shared__ double sex[PT];   // exp(eta~)            (unshifted, stm.py:1000,1088,1114)
-    __shared__ double sth[PT];   // stable_softmax(eta~) (stm.py:998,1083)
-    __shared__ double ssq[WAVE]; // sqrt(count) of the tile's words
-    __shared__ double sdv[PT];   // eta - mu broadcast (dense siginv only)
-    __shared__ double srow[PT];  // rowsum(c') per topic
-    double *bt = smem;
-    double *M = smem;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// doubles of dynamic LDS: max(T, M) + small vectors
+inline size_t post_lds_doubles(int n, int MLD) {
+    const size_t t = (size_t)PT * TLD, m = (size_t)n * MLD;
+    return (t > m ? t : m) + 5 * PT + 4 * TW;
+}
+
+template <int NB>
+__global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
+    constexpr int NT = NB * (NB + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double post_lds[];
     const int lane = threadIdx.x;
-    const int K = P.K, n = P.n;
+    const int K = P.K, n = P.n, MLD = P.MLD;
+    double *T = post_lds;  // [PT][TLD]
+    double *M = post_lds;  // [n][MLD] (after the word loop)
+    double *vec = post_lds + ((size_t)PT * TLD > (size_t)n * MLD ? (size_t)PT * TLD : (size_t)n * MLD);
+    double *sex = vec;            // exp(eta~)            (unshifted, stm.py:1000,1088,1114)
+    double *sth = vec + PT;       // stable_softmax(eta~) (stm.py:998,1083)
+    double *sdv = vec + 2 * PT;   // eta - mu broadcast (dense siginv only)
+    double *srow = vec + 3 * PT;  // rowsum(c') per topic
+    double *srd = vec + 4 * PT;   // 1 / diag(L)
+    double *wsq = vec + 5 * PT;   // per word of the tile: sqrt(c)
+    double *wS = wsq + TW;        //                       colsum S
+    double *wr = wS + TW;         //                       1 / S
+    double *ww = wr + TW;         //                       sqrt(c) / S
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
+    const bool isn = lane < n, isk = lane < K;
+    const int fr = lane & 15, fq = lane >> 4;  // MFMA fragment coordinates
 
-    {
-        const int64_t ticket = P.first + blockIdx.x;
-        if (ticket >= P.N) return;
+    v4d acc_nu[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc_nu[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
+        const int64_t ticket = P.first + tk;
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
         const int Nd = (int)(P.indptr[doc + 1] - p0);
-        const int ntile = (Nd + WAVE - 1) / WAVE;
         const int asp = P.aspect ? P.aspect[doc] : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
         double *bssT = P.beta_ssT + (size_t)asp * (size_t)P.V * K;
+        const bool dump_phi = P.phi_out && doc == P.phi_doc;
 
         // ---- eta~, theta (unshifted softmax, stm.py:547-549), stable softmax, exp(eta~)
-        const bool isn = lane < n, isk = lane < K;
         const double eta_i = isn ? P.eta[doc * n + lane] : 0.0;  // lane K-1 holds the appended 0
         const double mu_i = isn ? P.mu[doc * n + lane] : 0.0;
         const double ex = isk ? exp(eta_i) : 0.0;
@@ -88,67 +115,95 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
         const double es = isk ? exp(eta_i - m) : 0.0;
         const double ssum = wave_sum(es);
         const double ths = es / ssum;
-        if (lane < PT) { sex[lane] = ex; sth[lane] = isk ? ths : 0.0; }
+        __syncthreads();  // the previous document's readers of M / vec are done
+        sex[lane] = ex;
+        sth[lane] = isk ? ths : 0.0;
+        // topic rows K..63 of T stay zero for the whole document
+        for (int q = lane; q < PT * TLD; q += WAVE) T[q] = 0.0;
         __syncthreads();
 
         double csum = 0.0, ll = 0.0, rowc = 0.0;
         bool bad = false;
-        double acc[8][8];
+        v4d acc[NT];
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
-        const int br = lane & 7, bc = lane >> 3;
-        // topic rows K..63 of the tile stay zero for the whole document
-        for (int k = K; k < PT; ++k) bt[(size_t)k * MLD + lane] = 0.0;
+        for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int kc = (K + 3) >> 2;  // topics per quarter in step 2
 
-        for (int tile = 0; tile < ntile; ++tile) {
-            const int v = tile * WAVE + lane;
-            double *bcol = bt + lane;  // bt[k][lane]
-            if (v < Nd) {
-                const int idx = P.indices[p0 + v];
-                const double c = P.counts[p0 + v];
-                const double *row = bT + (size_t)idx * K;
-                double Ssum = 0.0, lls = 0.0;
-                for (int k = 0; k < K; ++k) {
-                    const double a = row[k] * sex[k];
-                    Ssum += a;                 // np.sum(a, 0)
-                    lls += sth[k] * a;         // theta @ (beta * exp(eta~)), stm.py:1088-1094
-                }
-                const double sq = sqrt(c);
-                const double w = sq / Ssum;    // update_z: sqrt(c) / colsum, stm.py:1115
-                ll += log(lls) * c;
-                csum += c;
-                double *bss = bssT + (size_t)idx * K;
-                for (int k = 0; k < K; ++k) {
-                    const double a = row[k] * sex[k];
-                    bcol[(size_t)k * MLD] = a * sq / Ssum;   // hessian b, stm.py:1001
-                    const double phi = a * w * sq;  // stm.py:1115-1116
-                    bad |= !(phi >= 0.0);
-                    if (!(P.debug_flags & 1)) unsafeAtomicAdd(bss + k, phi);  // beta_ss[:, idx] += phi, stm.py:588
-                    if (P.phi_out && doc == P.phi_doc) P.phi_out[(size_t)k * Nd + v] = phi;
-                }
-                ssq[lane] = sq;
-            } else {
-                for (int k = 0; k < K; ++k) bcol[(size_t)k * MLD] = 0.0;
-                ssq[lane] = 0.0;
+        for (int t0 = 0; t0 < Nd; t0 += TW) {
+            const int nw = Nd - t0 < TW ? Nd - t0 : TW;
+            const int my_idx = (lane < nw) ? P.indices[p0 + t0 + lane] : 0;
+            const double my_c = (lane < nw) ? P.counts[p0 + t0 + lane] : 0.0;
+            // -- 1. gather: 16 coalesced rows, transposed into T[topic][word]
+            double g[TW];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int idx = __builtin_amdgcn_readlane(my_idx, j);
+                g[j] = (isk && j < nw) ? bT[(size_t)idx * K + lane] : 0.0;
+            }
+            if (isk) {
+                double2 *row = reinterpret_cast<double2 *>(T + (size_t)lane * TLD);
+#pragma unroll
+                for (int j = 0; j < TW; j += 2) row[j >> 1] = make_double2(g[j], g[j + 1]);
             }
             __syncthreads();
-            // rowsum(c') with c' = b * sqrt(c), stm.py:1002,1011
-            if (isk)
-                for (int vv = 0; vv < WAVE; ++vv) rowc += bt[(size_t)lane * MLD + vv] * ssq[vv];
-            // b b^T, 8x8 register block per lane
-            if (!(P.debug_flags & 2))
-            for (int vv = 0; vv < WAVE; ++vv) {
-                const double *rp = bt + (size_t)(8 * br) * MLD + vv;
-                const double *cp = bt + (size_t)(8 * bc) * MLD + vv;
-                double ra[8], ca[8];
+            // -- 2. per-word sums, lane = (word fr, topic quarter fq)
+            {
+                double Sp = 0.0, Lp = 0.0;
+                const int k0 = fq * kc;
+                for (int kk = 0; kk < kc; ++kk) {
+                    const int k = k0 + kk;
+                    const double a = T[(size_t)k * TLD + fr] * sex[k];
+                    Sp += a;              // np.sum(a, 0)
+                    Lp += sth[k] * a;     // theta @ (beta * exp(eta~)), stm.py:1088-1094
+                }
+                Sp += __shfl_xor(Sp, 16); Sp += __shfl_xor(Sp, 32);
+                Lp += __shfl_xor(Lp, 16); Lp += __shfl_xor(Lp, 32);
+                if (lane < nw) {   // quarter 0 owns the word
+                    const double c = my_c;
+                    const double sq = sqrt(c);
+                    ll += log_pos(Lp) * c;
+                    csum += c;
+                    wsq[lane] = sq;
+                    wS[lane] = Sp;
+                    wr[lane] = 1.0 / Sp;
+                    ww[lane] = sq / Sp;   // update_z: sqrt(c) / colsum, stm.py:1115
+                }
+            }
+            __syncthreads();
+            // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
+            if (isk) {
+                double *trow = T + (size_t)lane * TLD;
+                for (int j = 0; j < nw; ++j) {
+                    const int idx = __builtin_amdgcn_readlane(my_idx, j);
+                    const double sq = wsq[j], Sj = wS[j], rj = wr[j], wj = ww[j];
+                    const double a = trow[j] * ex;
+                    // b = a*sqrt(c)/S (stm.py:1001): quotient by the shared divisor from its reciprocal
+                    const double num = a * sq;
+                    const double q0 = num * rj;
+                    const double b = fma(fma(-q0, Sj, num), rj, q0);
+                    const double phi = a * wj * sq;   // stm.py:1115-1116
+                    bad |= !(phi >= 0.0);
+                    rowc += b * sq;                   // rowsum(c'), c' = b*sqrt(c), stm.py:1002,1011
+                    trow[j] = b;
+                    if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, phi);  // stm.py:588
+                    if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = phi;
+                }
+            }
+            __syncthreads();
+            // -- 4. b b^T on the matrix cores, upper block triangle
+            if (!(P.debug_flags & 2)) {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) { ra[a] = rp[(size_t)a * MLD]; ca[a] = cp[(size_t)a * MLD]; }
+                for (int s = 0; s < TW / 4; ++s) {
+                    double f[NB];
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
+                    for (int b = 0; b < NB; ++b) f[b] = T[(size_t)(b * 16 + fr) * TLD + s * 4 + fq];
+                    int t = 0;
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) acc[a][b] = fma(ra[a], ca[b], acc[a][b]);
+                    for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                        for (int bj = bi; bj < NB; ++bj, ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
+                }
             }
             __syncthreads();
         }
@@ -157,21 +212,26 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
         ll = wave_sum(ll);
 
         // ---- assemble H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv
-        // (theta/rowc of row i live in lane i: fetch via LDS)
-        if (lane < PT) srow[lane] = rowc;
+        srow[lane] = rowc;
         __syncthreads();
+        {
+            int t = 0;
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int i = 8 * br + a;
+            for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int j = 8 * bc + b;
-                if (i < n && j < n) {
-                    double h = acc[a][b] - Ndoc * (sth[i] * sth[j]);
-                    if (i == j) h = h - srow[i] + Ndoc * sth[i];
-                    M[(size_t)i * MLD + j] = h + S[(size_t)i * n + j];
-                }
-            }
+                for (int bj = bi; bj < NB; ++bj, ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
+                        if (i < n && j < n) {
+                            double h = acc[t][r] - Ndoc * (sth[i] * sth[j]);
+                            if (i == j) h = h - srow[i] + Ndoc * sth[i];
+                            const double sij = (P.siginv_diag && i != j) ? 0.0 : S[(size_t)i * n + j];
+                            h = h + sij;
+                            M[(size_t)i * MLD + j] = h;
+                            if (bi != bj) M[(size_t)j * MLD + i] = h;
+                        }
+                    }
         }
         __syncthreads();
 
@@ -185,8 +245,8 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
                 double t = 0.0;
                 if (isn && lane >= j) {
                     t = (lane == j) ? diagA : M[(size_t)j * MLD + lane];
-                    for (int l = 0; l < j; ++l)
-                        t -= M[(size_t)lane * MLD + l] * M[(size_t)j * MLD + l];
+                    const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD;
+                    for (int l = 0; l < j; ++l) t -= ri[l] * rj[l];
                 }
                 const double d = lane_bcast(t, j);
                 if (!(d > 0.0)) { ok = false; break; }
@@ -224,7 +284,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
         };
         int path = 0;
         bool upper = false, fail = false;
-        bool ok = (P.debug_flags & 8) ? true : cholesky();                 // PD test of hessian(), stm.py:1017 (as Cholesky success)
+        bool ok = (P.debug_flags & 8) ? true : cholesky();  // PD test of hessian(), stm.py:1017 (as Cholesky success)
         if (!ok) {
             make_pd(); path = 1;              // stm.py:1019
             ok = cholesky();                  // stm.py:1020
@@ -251,7 +311,7 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
         if (P.pd_path) P.pd_path[doc] = path;
         if (fail) {
             atomicMax(P.err_flag, 3 /* STM_ERR_LINALG */);
-            return;
+            continue;
         }
         if (P.chol_out) {
             double *o = P.chol_out + (size_t)doc * n * n;
@@ -282,17 +342,19 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
         }
         q = wave_sum(q);
         P.bound[doc] = ll + (-det) - 0.5 * q - P.sigmaentropy;  // uniform store
+        if (P.debug_flags & 4) continue;
 
-        // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066), accumulated into sigma_ss
+        // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066)
         const double Rdiag = 1.0 / Ldiag;
-        if (P.debug_flags & 4) return;
+        srd[lane] = isn ? Rdiag : 0.0;
         if (!upper) {
             // R = U^{-1}, U = L^T: column c in lane c, rows from the bottom up; R overwrites the upper triangle
             for (int i = n - 2; i >= 0; --i) {
                 double t = 0.0;
                 if (isn && lane > i) {
-                    for (int l = i + 1; l < n; ++l) {
-                        const double rlc = (l == lane) ? Rdiag : (l < lane ? M[(size_t)l * MLD + lane] : 0.0);
+                    t = -(M[(size_t)lane * MLD + i] * Rdiag);  // the l == lane term
+                    for (int l = i + 1; l < n - 1; ++l) {
+                        const double rlc = (l < lane) ? M[(size_t)l * MLD + lane] : 0.0;
                         t -= M[(size_t)l * MLD + i] * rlc;
                     }
                 }
@@ -302,24 +364,67 @@ __global__ __launch_bounds__(64) void post_kernel(PostParams P) {
                 __syncthreads();
             }
         }
-        for (int i = 0; i < n; ++i) {
-            double t = 0.0;
-            const double rii = lane_bcast(Rdiag, i);
-            if (isn) {
-                if (upper) t = (lane == i) ? Rdiag * Rdiag : 0.0;
-                else {
-                    const int l0 = i > lane ? i : lane;
-                    for (int l = l0; l < n; ++l) {
-                        const double ril = (l == i) ? rii : M[(size_t)i * MLD + l];
-                        const double rjl = (l == lane) ? Rdiag : M[(size_t)lane * MLD + l];
-                        t += ril * rjl;
+        __syncthreads();
+        // nu = R R^T on the matrix cores; fragment R[b*16 + fr][s4 + fq], zero below the diagonal
+        v4d nud[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) nud[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int s4 = 0; s4 < n; s4 += 4) {
+            const int col = s4 + fq;
+            double f[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int row = b * 16 + fr;
+                double v = 0.0;
+                if (row < n && col < n) {
+                    if (col == row) v = srd[row];
+                    else if (col > row && !upper) v = M[(size_t)row * MLD + col];
+                }
+                f[b] = v;
+            }
+            int t = 0;
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                for (int bj = bi; bj < NB; ++bj, ++t)
+                    nud[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], nud[t], 0, 0, 0);
+        }
+        {
+            int t = 0;
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                for (int bj = bi; bj < NB; ++bj, ++t) {
+                    acc_nu[t] += nud[t];   // sigma_ss += nu, stm.py:582
+                    if (P.nu_out) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
+                            if (i < n && j < n) {
+                                P.nu_out[(size_t)doc * n * n + (size_t)i * n + j] = nud[t][r];
+                                P.nu_out[(size_t)doc * n * n + (size_t)j * n + i] = nud[t][r];
+                            }
+                        }
                     }
                 }
-                unsafeAtomicAdd(sig_acc + (size_t)i * n + lane, t);  // sigma_ss += nu, stm.py:582
-                if (P.nu_out) P.nu_out[(size_t)doc * n * n + (size_t)i * n + lane] = t;
-            }
         }
-        __syncthreads();
+    }
+
+    // ---- one flush of the workgroup's nu sum into its replica of sigma_ss
+    {
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+            for (int bj = bi; bj < NB; ++bj, ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
+                    if (i < n && j < n) {
+                        unsafeAtomicAdd(sig_acc + (size_t)i * n + j, acc_nu[t][r]);
+                        if (bi != bj) unsafeAtomicAdd(sig_acc + (size_t)j * n + i, acc_nu[t][r]);
+                    }
+                }
     }
 }
 
