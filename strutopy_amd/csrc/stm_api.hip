@@ -490,8 +490,11 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
         // persistent single-wave workgroups: as many as the LDS / register budget keeps resident
         using PostFn = void (*)(stm::PostParams);
         const int nb = (K + 15) / 16;
-        const PostFn pf = nb <= 1 ? stm::post_kernel<1> : nb == 2 ? stm::post_kernel<2>
-                        : nb == 3 ? stm::post_kernel<3> : stm::post_kernel<4>;
+        const bool dumps = pp.nu_out != nullptr;
+        const PostFn pf = dumps ? (nb <= 1 ? stm::post_kernel<1, true> : nb == 2 ? stm::post_kernel<2, true>
+                                   : nb == 3 ? stm::post_kernel<3, true> : stm::post_kernel<4, true>)
+                                : (nb <= 1 ? stm::post_kernel<1, false> : nb == 2 ? stm::post_kernel<2, false>
+                                   : nb == 3 ? stm::post_kernel<3, false> : stm::post_kernel<4, false>);
         pp.MLD = n | 1;
         const size_t lds = stm::post_lds_doubles(n, pp.MLD) * sizeof(double);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -62,14 +62,18 @@ constexpr int TLD = 18;   // leading dimension of T: MFMA fragment reads are con
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+#ifndef STM_POST_WPE
+#define STM_POST_WPE 2   // waves per SIMD the post kernel is register-budgeted for
+#endif
+
 // doubles of dynamic LDS: max(T, M) + small vectors
 inline size_t post_lds_doubles(int n, int MLD) {
     const size_t t = (size_t)PT * TLD, m = (size_t)n * MLD;
     return (t > m ? t : m) + 5 * PT + 4 * TW;
 }
 
-template <int NB>
-__global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
+template <int NB, bool DUMP>
+__global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     constexpr int NT = NB * (NB + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) double post_lds[];
     const int lane = threadIdx.x;
@@ -211,9 +215,10 @@ __global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
 
-        // ---- assemble H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv
+        // ---- assemble H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv:
+        // the MFMA tiles go to LDS raw, then lane i finishes row i (keeps the 4*NT tile elements
+        // from being in flight at once)
         srow[lane] = rowc;
-        __syncthreads();
         {
             int t = 0;
 #pragma unroll
@@ -224,14 +229,21 @@ __global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
                     for (int r = 0; r < 4; ++r) {
                         const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
                         if (i < n && j < n) {
-                            double h = acc[t][r] - Ndoc * (sth[i] * sth[j]);
-                            if (i == j) h = h - srow[i] + Ndoc * sth[i];
-                            const double sij = (P.siginv_diag && i != j) ? 0.0 : S[(size_t)i * n + j];
-                            h = h + sij;
-                            M[(size_t)i * MLD + j] = h;
-                            if (bi != bj) M[(size_t)j * MLD + i] = h;
+                            M[(size_t)i * MLD + j] = acc[t][r];
+                            if (bi != bj) M[(size_t)j * MLD + i] = acc[t][r];
                         }
                     }
+        }
+        __syncthreads();
+        if (isn) {
+            double *mi = M + (size_t)lane * MLD;
+            const double thi = sth[lane];
+            for (int j = 0; j < n; ++j) {
+                double h = mi[j] - Ndoc * (thi * sth[j]);
+                if (j == lane) h = h - rowc + Ndoc * thi;
+                const double sij = (P.siginv_diag && j != lane) ? 0.0 : S[(size_t)lane * n + j];
+                mi[j] = h + sij;
+            }
         }
         __syncthreads();
 
@@ -282,38 +294,33 @@ __global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
                     o[(size_t)lane * n + j] = val;
                 }
         };
+        // One Cholesky site for every stage of the reference's PD ladder (five inlined copies put
+        // the fallback ones on cold paths, where the register allocator parks its spill reloads):
+        //   0 hessian(): PD test as Cholesky success (stm.py:1017)   1 after make_pd (stm.py:1019-1020)
+        //   2 +1e-5 (stm.py:1021), decompose_hessian's np.linalg.cholesky (stm.py:1040)
+        //   3 after make_pd (stm.py:1043)   4 scipy cholesky (UPPER) of make_pd(H) + 1e-5 I (stm.py:1046-1048)
         int path = 0;
         bool upper = false, fail = false;
-        bool ok = (P.debug_flags & 8) ? true : cholesky();  // PD test of hessian(), stm.py:1017 (as Cholesky success)
-        if (!ok) {
-            make_pd(); path = 1;              // stm.py:1019
-            ok = cholesky();                  // stm.py:1020
-            if (!ok) {
-                if (isn) diagA += 1e-5;       // stm.py:1021
-                path = 2;
-                dump(P.hess_out, false);
-                ok = cholesky();              // decompose_hessian, stm.py:1040
-                if (!ok) {
-                    make_pd();                // stm.py:1043
-                    ok = cholesky();
-                    if (!ok) {                // stm.py:1046-1048: scipy cholesky (UPPER) of make_pd(H)+1e-5 I
-                        make_pd();
-                        const double keep = diagA;
-                        if (isn) diagA += 1e-5;
-                        ok = cholesky();
-                        diagA = keep;
-                        upper = true;
-                        if (!ok) fail = true;
-                    }
-                }
-            } else dump(P.hess_out, false);
-        } else dump(P.hess_out, false);
+        double keep = 0.0;
+        for (int attempt = 0;; ++attempt) {
+            if (DUMP && attempt == 2) dump(P.hess_out, false);
+            const bool ok = (attempt == 0 && (P.debug_flags & 8)) ? true : cholesky();
+            if (attempt == 4) { diagA = keep; upper = true; fail = !ok; break; }
+            if (ok) {
+                if (DUMP && attempt < 2) dump(P.hess_out, false);
+                break;
+            }
+            if (attempt == 0) { make_pd(); path = 1; }
+            else if (attempt == 1) { if (isn) diagA += 1e-5; path = 2; }
+            else if (attempt == 2) { make_pd(); }
+            else { make_pd(); keep = diagA; if (isn) diagA += 1e-5; }
+        }
         if (P.pd_path) P.pd_path[doc] = path;
         if (fail) {
             atomicMax(P.err_flag, 3 /* STM_ERR_LINALG */);
             continue;
         }
-        if (P.chol_out) {
+        if (DUMP && P.chol_out) {
             double *o = P.chol_out + (size_t)doc * n * n;
             if (isn)
                 for (int j = 0; j < n; ++j) {
@@ -365,10 +372,13 @@ __global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
             }
         }
         __syncthreads();
-        // nu = R R^T on the matrix cores; fragment R[b*16 + fr][s4 + fq], zero below the diagonal
-        v4d nud[NT];
+        // nu = R R^T on the matrix cores, accumulated straight into the workgroup's running sum
+        // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq], zero below the diagonal
+        v4d nud[DUMP ? NT : 1];
+        if (DUMP) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) nud[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < NT; ++t) { nud[t] = acc_nu[t]; acc_nu[t] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+        }
         for (int s4 = 0; s4 < n; s4 += 4) {
             const int col = s4 + fq;
             double f[NB];
@@ -387,25 +397,25 @@ __global__ __launch_bounds__(64, 2) void post_kernel(PostParams P) {
             for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                 for (int bj = bi; bj < NB; ++bj, ++t)
-                    nud[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], nud[t], 0, 0, 0);
+                    acc_nu[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc_nu[t], 0, 0, 0);
         }
-        {
+        if (DUMP) {  // parity-test build: per-document nu
             int t = 0;
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                 for (int bj = bi; bj < NB; ++bj, ++t) {
-                    acc_nu[t] += nud[t];   // sigma_ss += nu, stm.py:582
                     if (P.nu_out) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
                             if (i < n && j < n) {
-                                P.nu_out[(size_t)doc * n * n + (size_t)i * n + j] = nud[t][r];
-                                P.nu_out[(size_t)doc * n * n + (size_t)j * n + i] = nud[t][r];
+                                P.nu_out[(size_t)doc * n * n + (size_t)i * n + j] = acc_nu[t][r];
+                                P.nu_out[(size_t)doc * n * n + (size_t)j * n + i] = acc_nu[t][r];
                             }
                         }
                     }
+                    acc_nu[t] += nud[t];
                 }
         }
     }
