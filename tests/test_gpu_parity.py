@@ -181,6 +181,27 @@ def test_stm_class_reproduces_reference_traces(oracle):
     m.close()
 
 
+def test_rccl_all_reduce_path_single_rank():
+    """The RCCL binding (dlopen, ncclCommInitRank, ncclAllReduce on the packed device buffer) with a
+    one-rank communicator: the reduction is the identity, so every statistic must come back unchanged."""
+    from strutopy_amd.engine import HipEstepEngine
+    g = load_golden("c1_k10")
+    e = HipEstepEngine(0)
+    e.set_corpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+    e.set_topics(int(g["K"]))
+    e.put_beta(g["beta0"]); e.put_mu(g["it0_mu_in"]); e.put_eta(g["it0_eta_in"])
+    bound = e.estep(g["it0_siginv"], float(g["it0_sigmaentropy"]))
+    beta_ss, sigma_ss = e.get_beta_ss(), e.get_sigma_ss()
+    e.comm_init(e.comm_unique_id(), 0, 1)
+    extra = np.arange(1.0, 40.0)
+    b2, extra2 = e.allreduce_suffstats(extra)
+    assert b2 == bound and np.array_equal(extra2, extra)
+    assert np.array_equal(e.get_beta_ss(), beta_ss) and np.array_equal(e.get_sigma_ss(), sigma_ss)
+    small = np.linspace(-1, 1, 81).reshape(9, 9)
+    assert np.array_equal(e.allreduce_small(small), small)
+    e.close()
+
+
 @pytest.fixture(scope="module")
 def full_size():
     """BASELINE.json configs[1]: 100k synthetic documents x 150 words, V=10k, K=50."""
