@@ -72,6 +72,7 @@ SIGNATURES = {
 # not part of the public header: debug dumps used by the parity tests
 _DEBUG_SIGNATURES = {
     "stm_debug_get_mats": (C.c_int, [_h, _dp, _dp, _dp]),
+    "stm_debug_get_prof": (C.c_int, [_h, C.POINTER(C.c_longlong)]),
 }
 
 _LIB = None

@@ -99,10 +99,13 @@ struct stm_handle {
     struct Group { int64_t first, count; int ld; size_t lds_bytes; bool global; };
     std::vector<Group> groups;
     int kreg = 0;                // register-resident topic count of the solver instantiation (0: none)
+    int nw = 1;                  // wavefronts per document in the solver
+    int KP = 0;                  // slab row length (doubles)
     // optional dumps
     double *d_phi = nullptr;
     int64_t phi_doc = -1;
     double *d_hess = nullptr, *d_chol = nullptr, *d_nu = nullptr;
+    long long *d_prof = nullptr;
     // M-step
     int p = 0;
     double *d_X = nullptr, *d_mom = nullptr, *d_gamma = nullptr, *d_cov = nullptr;
@@ -125,9 +128,18 @@ static int use_device(stm_handle *h) {
 
 using SolverFn = void (*)(stm::SolverParams);
 
-// solver instantiations: KREG topics of the first 64 words in registers (0: none), LDS or global slab
-static SolverFn solver_fn(int kreg, bool global_slab) {
+// solver instantiations: KREG topics of the register-resident words (0: none), LDS or global slab,
+// one or two wavefronts per document
+static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1) {
     if (global_slab) return stm::solver_kernel<1, 0, true>;
+    if (nw == 2) {
+        switch (kreg) {
+        case 16: return stm::solver_kernel<1, 16, false, 2>;
+        case 32: return stm::solver_kernel<1, 32, false, 2>;
+        case 50: return stm::solver_kernel<1, 50, false, 2>;
+        default: return stm::solver_kernel<1, 64, false, 2>;
+        }
+    }
     switch (kreg) {
     case 16: return stm::solver_kernel<1, 16, false>;
     case 32: return stm::solver_kernel<1, 32, false>;
@@ -141,18 +153,22 @@ static SolverFn solver_fn(int kreg, bool global_slab) {
 static int slab_row(int K) { return ((std::max(K, 2) - 2 + 3) / 4) * 4 + 2; }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
-constexpr size_t LDS_STATIC = 2048;   // se / sv / sw of the solver kernel, rounded up
+constexpr size_t LDS_STATIC = 3584;   // static LDS of the solver kernel (se, sv, sw, mailbox), rounded up
 
 // Cut the longest-first document order into launches of equal LDS occupancy.
 static int plan_solver(stm_handle *h) {
     const int K = h->K;
-    // STM_SOLVER_MODE: 0 auto (registers + LDS), 1 LDS only, 2 global slab only (v1 data path)
+    // STM_SOLVER_MODE: 0 auto (two waves per document, registers + LDS), 3 one wave (registers + LDS),
+    // 1 one wave, LDS only, 2 one wave, global slab only (v1 data path)
     const int mode = env_int("STM_SOLVER_MODE", 0);
     h->kreg = 0;
-    if (mode == 0) h->kreg = K <= 16 ? 16 : K <= 32 ? 32 : K <= 50 ? 50 : 64;
-    const int vreg = h->kreg > 0 ? 64 : 0;
+    h->nw = 1;
+    if (mode == 0 || mode == 3) h->kreg = K <= 16 ? 16 : K <= 32 ? 32 : K <= 50 ? 50 : 64;
+    if (mode == 0) h->nw = 2;
+    const int vreg = h->kreg > 0 ? 64 * h->nw : 0;
     const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
-    const int KP = slab_row(K);
+    const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
+    h->KP = KP;
     auto lds_of = [&](int nd) { return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double); };
     auto per_cu = [&](int nd) -> int {
         const size_t b = ((lds_of(nd) + LDS_STATIC + 511) / 512) * 512;
@@ -183,7 +199,7 @@ static int plan_solver(stm_handle *h) {
         i = j;
     }
     if (max_dyn > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false),
+        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn);
         if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
@@ -230,7 +246,7 @@ void stm_destroy(stm_handle *h) {
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
     dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
-    dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu);
+    dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu); dfree(h->d_prof);
     dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack);
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -340,6 +356,11 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->beta_set = false;
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu);
+    dfree(h->d_prof);
+    if (env_int("STM_DEBUG_PROF", 0)) {
+        if (int rc = dalloc(&h->d_prof, N * 40)) return rc;
+        HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * N * 40));
+    }
     if (env_int("STM_DEBUG_DUMP", 0)) {
         if (int rc = dalloc(&h->d_hess, N * n * n)) return rc;
         if (int rc = dalloc(&h->d_chol, N * n * n)) return rc;
@@ -437,6 +458,12 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     for (int i = 0; i < n && diag; ++i)
         for (int j = 0; j < n; ++j)
             if (i != j && siginv[(size_t)i * n + j] != 0.0) { diag = 0; break; }
+    double sig_bound = 0.0;   // max absolute row sum >= largest eigenvalue (siginv is symmetric)
+    for (int i = 0; i < n; ++i) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) r += fabs(siginv[(size_t)i * n + j]);
+        sig_bound = std::max(sig_bound, r);
+    }
     const size_t KV = (size_t)h->A * K * h->V;
     HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)h->nrep * n * n, h->stream));
@@ -450,13 +477,14 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     }
 
     stm::SolverParams sp{};
-    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = slab_row(K);
+    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = h->KP;
     sp.indptr = h->d_indptr; sp.indices = h->d_indices; sp.counts = h->d_counts; sp.aspect = h->d_aspect;
-    sp.betaT = h->d_betaT; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag;
+    sp.betaT = h->d_betaT; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag; sp.sig_bound = sig_bound;
     sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
     sp.order = h->d_order; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
     sp.err_flag = h->d_err;
     sp.debug_flags = env_int("STM_DEBUG_FLAGS", 0);
+    sp.prof = h->d_prof;
 
     stm::PostParams pp{};
     pp.N = h->N; pp.K = K; pp.n = n; pp.V = h->V;
@@ -473,7 +501,8 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
-            const SolverFn fn = gr.global ? solver_fn(0, true) : solver_fn(h->kreg, false);
+            const SolverFn fn = gr.global ? solver_fn(0, true) : solver_fn(h->kreg, false, h->nw);
+            const unsigned bdim = gr.global ? 64u : 64u * (unsigned)h->nw;
             sp.ld = gr.ld;
             int64_t step = h->chunk;
             if (gr.global)
@@ -481,7 +510,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
             for (int64_t off = 0; off < gr.count; off += step) {
                 sp.first = gr.first + off;
                 const unsigned g = (unsigned)std::min<int64_t>(step, gr.count - off);
-                hipLaunchKernelGGL(fn, dim3(g), dim3(64), gr.lds_bytes, h->stream, sp);
+                hipLaunchKernelGGL(fn, dim3(g), dim3(bdim), gr.lds_bytes, h->stream, sp);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -533,6 +562,14 @@ int stm_get_phi(stm_handle *h, int64_t doc, double *phi) {
     if (doc != h->phi_doc || !h->d_phi) return fail(STM_ERR_INVALID, "stm_get_phi: only the last document's phi is kept (stm.py:1116)");
     const size_t nd = (size_t)(h->h_indptr[doc + 1] - h->h_indptr[doc]);
     return get_vec(h, phi, h->d_phi, (size_t)h->K * nd);
+}
+
+int stm_debug_get_prof(stm_handle *h, long long *out) {
+    NEED_MODEL(h);
+    if (!h->d_prof) return fail(STM_ERR_INVALID, "set STM_DEBUG_PROF=1 before stm_set_topics");
+    HIP_TRY(hipMemcpy(out, h->d_prof, sizeof(long long) * (size_t)h->N * 40, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * (size_t)h->N * 40));
+    return STM_OK;
 }
 
 int stm_debug_get_mats(stm_handle *h, double *hess, double *chol, double *nu) {

@@ -26,6 +26,13 @@
 
 namespace stm {
 
+// LDS hand-off between lanes of ONE wave: the LDS executes a wave's operations in order, so only
+// the compiler has to be kept from reordering them (a workgroup barrier here would also have to
+// be matched by the other wave of a two-wave workgroup)
+#define STM_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// same, when the hand-off also goes through global memory (the BFGS matrix slab): wait for the stores
+#define STM_WAVE_SYNC_MEM() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 struct SolverParams {
     int64_t N;
     int K, n, V;
@@ -38,6 +45,7 @@ struct SolverParams {
     double *eta;            // [N][n] in/out
     const double *siginv;   // [n][n]
     int siginv_diag;        // 1: off-diagonals are exactly zero (what stm.py:501 produces)
+    double sig_bound;       // upper bound on the largest eigenvalue of siginv (max absolute row sum)
     double *slab_beta;      // GLOBAL_SLAB variant only: [grid][(K+2)][ld]
     double *slab_H;         // [grid][n][n]
     int ld;                 // slab capacity in words (held outside registers), per launch
@@ -47,6 +55,8 @@ struct SolverParams {
     int32_t *status, *nit, *nfev, *njev;
     int32_t *err_flag;
     int debug_flags;        // bit0: skip the BFGS loop (bring-up aid)
+    long long *prof;        // optional [N][40] shader-clock totals per document: [0] init, [1] evaluations, [2] state machine,
+                            // [3] BFGS update, [8+st] cycles in state st, [24+st] visits of state st
 };
 
 enum : int {
@@ -55,10 +65,17 @@ enum : int {
     S_ACCEPT2, S_FINISH
 };
 
-// scipy/optimize/_dcsrch.py:502-728 dcstep (wave-uniform scalars)
-__device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy,
-                                       double &dy, double &stp, double fp, double dp, bool &brackt,
-                                       double stpmin, double stpmax) {
+// scipy/optimize/_dcsrch.py:502-728 dcstep (wave-uniform scalars).  State in and out BY VALUE and
+// the final interval update as selects: with reference parameters the conditional swaps of
+// (stx, fx, dx) / (sty, fy, dy) became an indexed stack array, i.e. scratch-memory round trips in
+// the middle of every line-search step.
+struct DcStep {
+    double stx, fx, dx, sty, fy, dy, stp;
+    bool brackt;
+};
+__device__ __forceinline__ DcStep dcstep(DcStep S, double fp, double dp, double stpmin, double stpmax) {
+    const double stx = S.stx, fx = S.fx, dx = S.dx, sty = S.sty, fy = S.fy, dy = S.dy, stp = S.stp;
+    bool brackt = S.brackt;
     const double sgnd = np_sign(dp) * np_sign(dx);
     double stpf, stpc, stpq, theta, s, gamma, p, q, r;
     if (fp > fx) {
@@ -123,13 +140,18 @@ __device__ __forceinline__ void dcstep(double &stx, double &fx, double &dx, doub
         } else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
-    if (fp > fx) {
-        sty = stp; fy = fp; dy = dp;
-    } else {
-        if (sgnd < 0) { sty = stx; fy = fx; dy = dx; }
-        stx = stp; fx = fp; dx = dp;
-    }
-    stp = stpf;
+    // update the interval which contains a minimizer
+    const bool hi = fp > fx, neg = sgnd < 0;
+    DcStep R;
+    R.sty = hi ? stp : (neg ? stx : sty);
+    R.fy = hi ? fp : (neg ? fx : fy);
+    R.dy = hi ? dp : (neg ? dx : dy);
+    R.stx = hi ? stx : stp;
+    R.fx = hi ? fx : fp;
+    R.dx = hi ? dx : dp;
+    R.stp = stpf;
+    R.brackt = brackt;
+    return R;
 }
 
 // scipy/optimize/_linesearch.py:477-508 _cubicmin; false == None
@@ -168,17 +190,32 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
     return true;
 }
 
-template <int VPL, int KREG, bool GLOBAL_SLAB>
-__global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
+// NW = 1: one wavefront per document.
+// NW = 2: two wavefronts per document (VPL = 1, KREG > 0).  Wave 0 runs the solver state machine
+// and evaluates words 0..63 (registers) + the slab; wave 1 is an evaluation server that holds words
+// 64..127 in ITS registers and computes, per request, its share of the data term, the prior's
+// quadratic form and the gradient df -- the independent pieces of one objective evaluation run on
+// two SIMD slots at once, and the LDS slab shrinks to the words beyond 128 (two barriers per
+// evaluation; everything the solver's control flow sees still passes through wave 0).
+template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1>
+__global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
     constexpr int KMAX = 64 * VPL;
-    constexpr int VREG = (KREG > 0) ? WAVE : 0;      // words held in registers
+    constexpr int VREG = (KREG > 0) ? WAVE * NW : 0;  // words held in registers
     constexpr int KR = (KREG > 0) ? KREG : 2;
     static_assert(KREG % 2 == 0 && KREG <= KMAX, "KREG must be even and <= 64*VPL");
+    static_assert(NW == 1 || (NW == 2 && VPL == 1 && KREG > 0 && !GLOBAL_SLAB), "two-wave form: VPL = 1, registers + LDS");
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld]
     __shared__ __attribute__((aligned(16))) double se[KMAX + 2];  // exp(eta~ - m), broadcast to every lane
     __shared__ double sv[KMAX + 1];  // vector broadcast (matvec operand / s)
     __shared__ double sw[KMAX + 1];  // vector broadcast (w = H y)
-    const int lane = threadIdx.x;
+    __shared__ double svb[NW == 2 ? KMAX + 1 : 1];  // wave 1's private broadcast vector
+    // wave 0 <-> wave 1 mailbox (NW = 2)
+    __shared__ double xch_xt[NW == 2 ? WAVE : 1];   // trial point
+    __shared__ double xch_gv[NW == 2 ? WAVE : 1];   // df at the trial point / partial g0
+    __shared__ double xch_res[8];                   // [0] data-term share, [1] quadratic form, [2] m, [4..5] word-count shares
+    __shared__ int xch_cmd[4];                      // [0] request bits (1 f, 2 g, 4 exit), [1..2] bad-beta flags
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = NW == 2 ? (int)(threadIdx.x >> 6) : 0;
     const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
     double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
     double *crow = slab + (size_t)KP * ld;  // counts of the slab words
@@ -195,18 +232,19 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
         const int Nd = (int)(P.indptr[doc + 1] - p0);
-        const int NdL = Nd > VREG ? Nd - VREG : 0;  // words in the slab (<= ld)
+        const int NdL = (Nd > VREG && wv == 0) ? Nd - VREG : 0;  // words in the slab (<= ld), wave 0's
         const int asp = P.aspect ? P.aspect[doc] : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
 
         // ---- gather beta_d (stm.py:614-617), lane = word; assert beta >= 0 (stm.py:534)
         double csum = 0.0;
         bool bad = false;
-        double breg[KR];   // beta_d[:, lane] of word `lane` (KREG > 0)
+        double breg[KR];   // beta_d[:, word] of word `wv*64 + lane` (KREG > 0)
         double c0 = 0.0, w0 = 0.0;
+        const int wreg = wv * WAVE + lane;  // this lane's register-resident word
         if (KREG > 0) {
-            const bool act = lane < Nd;
-            const int idx = act ? P.indices[p0 + lane] : 0;
+            const bool act = wreg < Nd;
+            const int idx = act ? P.indices[p0 + wreg] : 0;
             const double *row = bT + (size_t)idx * K;
             double colsum = 0.0;
 #pragma unroll
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                 colsum += b;
             }
             if (act) {
-                c0 = P.counts[p0 + lane];
+                c0 = P.counts[p0 + wreg];
                 w0 = c0 / colsum;
                 csum += c0;
             }
@@ -240,13 +278,23 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
             csum += c;
         }
         // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
-        for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
-        __syncthreads();  // slab stores -> visible to the whole wave
-        if (wave_any(bad)) {
+        if (wv == 0)
+            for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
+        double csum_all = wave_sum(csum);
+        bool bad_all = wave_any(bad);
+        if (NW == 2) {
+            if (lane == 0) { xch_res[4 + wv] = csum_all; xch_cmd[1 + wv] = bad_all ? 1 : 0; }
+            __syncthreads();
+            csum_all = xch_res[4] + xch_res[5];
+            bad_all = (xch_cmd[1] | xch_cmd[2]) != 0;
+        } else {
+            __syncthreads();  // slab stores -> visible to the whole wave
+        }
+        if (bad_all) {
             atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
             return;
         }
-        const ud Ndoc = (double)(long long)wave_sum(csum);  // int(np.sum(word_count)), stm.py:933
+        const ud Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
 
         // ---- lane vectors
         double x[VPL], g[VPL], p[VPL], xt[VPL], gv[VPL], mu[VPL], sd[VPL], g0[VPL];
@@ -260,12 +308,12 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
             g[r] = 0.0; p[r] = 0.0; xt[r] = 0.0; gv[r] = 0.0; g0[r] = 0.0;
         }
         // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
-        auto g0_slab = [&](int k) -> double {
+        auto g0_slab = [&](int k) __attribute__((always_inline)) -> double {
             double t = 0.0;
             for (int vv = lane; vv < NdL; vv += WAVE) t += slab[(size_t)vv * KP + k] * wrow[vv];
             return t;
         };
-        auto g0_put = [&](int k, double t) {
+        auto g0_put = [&](int k, double t) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < VPL; ++r)
                 if (k == lane + WAVE * r) g0[r] = t;
@@ -278,10 +326,13 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
             for (int k = 0; k < n; ++k) g0_put(k, wave_sum(g0_slab(k)));
         }
 
+        long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0, t_init = 0, t_eval = 0, t_sm = 0, t_upd = 0;
         int nfev = 0, njev = 0;
+        double *svx = (NW == 2 && wv == 1) ? svb : sv;  // this wave's private broadcast vector
 
-        // f(eta): stm.py:920-944
-        auto eval_F = [&]() -> double {
+        // ---- pieces of f(eta), stm.py:920-944
+        // m = max(eta~), exp(eta~ - m) -> se[], multiplicity of the maximum, sum of the other exponentials
+        auto head_F = [&](double &m_out, int &icnt_out, double &ssum_out, double &e_out) __attribute__((always_inline)) {
             double mloc = 0.0;  // the appended 0 of eta~
 #pragma unroll
             for (int r = 0; r < VPL; ++r)
@@ -295,23 +346,26 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                 const double val = (i < n) ? xt[r] : 0.0;
                 const double e = exp(val - m);
                 if (i < K) se[i] = e;
+                if (r == 0) e_out = (i < K) ? e : 0.0;
                 const bool ismax = (i < K) && (val == m);
                 icnt += __popcll(__ballot(ismax));
                 ssum += (i < K && !ismax) ? e : 0.0;
             }
-            __syncthreads();
-            ssum = wave_sum(ssum);
-            // scipy.special.logsumexp: log1p(s/m) + log(m) + a_max (m = multiplicity of the maximum)
-            double lse;
-            if (icnt == 1) {
-                lse = log1p_pos(ssum) + m;          // s/1, + log(1)
-            } else {
-                const double cnt = (double)icnt;
-                lse = log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
-            }
+            m_out = m; icnt_out = icnt; ssum_out = ssum;
+        };
+        // scipy.special.logsumexp: log1p(s/m) + log(m) + a_max (m = multiplicity of the maximum)
+        auto lse_F = [&](double m, int icnt, double ssum_lane) __attribute__((always_inline)) -> double {
+            const double ssum = wave_sum(ssum_lane);
+            if (icnt == 1) return log1p_pos(ssum) + m;  // s/1, + log(1)
+            const double cnt = (double)icnt;
+            return log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
+        };
+        // c . (m + log(exp(eta~ - m) @ beta_d)) restricted to this wave's words, per lane.
+        // (e_lane: exp(eta~ - m) of topic `lane`, 0 beyond K -- kept for broadcast experiments.)
+        auto data_F = [&](double m, double e_lane, const int NdL) __attribute__((always_inline)) -> double {  // NdL shadows: slab words to cover
             double part = 0.0;
             const double2 *se2 = reinterpret_cast<const double2 *>(se);
-            if (KREG > 0) {  // words 0..63: beta_d column in registers, two FMA chains
+            if (KREG > 0) {  // register-resident word: beta_d column in registers, two FMA chains
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int k = 0; k < KR; k += 2) {
@@ -324,7 +378,7 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const double lg = m + log_pos(s0 + s1);
-                part = (lane < Nd) ? c0 * lg : 0.0;
+                part = (wreg < Nd) ? c0 * lg : 0.0;
             }
             // slab words: every lane streams its word's row (ds_read_b128), two 64-word tiles per
             // sweep so the broadcast se pair is read once for both
@@ -360,7 +414,10 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                     part += (va < NdL) ? crow[ia] * la : 0.0;
                 }
             }
-            part = wave_sum(part);
+            return part;
+        };
+        // (eta - mu)^T siginv (eta - mu), wave-summed
+        auto quad_F = [&]() __attribute__((always_inline)) -> double {
             double q = 0.0;
             if (sdiag) {
 #pragma unroll
@@ -372,25 +429,36 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
             } else {
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
-                    if (lane + WAVE * r < n) sv[lane + WAVE * r] = xt[r] - mu[r];
-                __syncthreads();
+                    if (lane + WAVE * r < n) svx[lane + WAVE * r] = xt[r] - mu[r];
+                STM_WAVE_SYNC();
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) {
                     const int i = lane + WAVE * r;
                     if (i < n) {
                         double t = 0.0;
-                        for (int j = 0; j < n; ++j) t += sv[j] * S[(size_t)j * n + i];
-                        q += t * sv[i];
+                        for (int j = 0; j < n; ++j) t += svx[j] * S[(size_t)j * n + i];
+                        q += t * svx[i];
                     }
                 }
+                STM_WAVE_SYNC();
             }
-            q = wave_sum(q);
-            __syncthreads();
+            return wave_sum(q);
+        };
+        // the whole of f on one wave (NW = 1)
+        auto eval_F = [&]() __attribute__((always_inline)) -> double {
+            double m, ssum, e_lane = 0.0;
+            int icnt;
+            head_F(m, icnt, ssum, e_lane);
+            STM_WAVE_SYNC();
+            double lse = lse_F(m, icnt, ssum);
+            double part = wave_sum(data_F(m, e_lane, NdL));
+            double q = quad_F();
+            STM_WAVE_SYNC();
             return 0.5 * q - (part - Ndoc * lse);
         };
 
         // df(eta): stm.py:946-958 (data term g0 has no eta dependence)
-        auto eval_DF = [&]() {
+        auto eval_DF = [&]() __attribute__((always_inline)) {
             double ex[VPL];
             double sl = 0.0;
 #pragma unroll
@@ -407,38 +475,86 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
             } else {
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
-                    if (lane + WAVE * r < n) sv[lane + WAVE * r] = xt[r] - mu[r];
-                __syncthreads();
+                    if (lane + WAVE * r < n) svx[lane + WAVE * r] = xt[r] - mu[r];
+                STM_WAVE_SYNC();
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) {
                     const int i = lane + WAVE * r;
                     double t = 0.0;
                     if (i < n)
-                        for (int j = 0; j < n; ++j) t += S[(size_t)i * n + j] * sv[j];
+                        for (int j = 0; j < n; ++j) t += S[(size_t)i * n + j] * svx[j];
                     gv[r] = (i < n) ? t - (g0[r] - scale * ex[r]) : 0.0;
                 }
-                __syncthreads();
+                STM_WAVE_SYNC();
             }
         };
 
-        auto dot = [&](const double (&a)[VPL], const double (&b)[VPL]) -> double {
+        // ---- two-wave form: wave 1 serves evaluation requests until wave 0 posts "exit"
+        if (NW == 2) {
+            // df needs the data term g0 of ALL words: wave 0 hands its share to wave 1
+            if (wv == 0 && lane < n) xch_gv[lane] = g0[0];
+            __syncthreads();
+            if (wv == 1) {
+                if (lane < n) g0[0] += xch_gv[lane];
+                for (;;) {
+                    __syncthreads();  // request posted: xch_cmd[0], trial point, exp(eta~ - m) in se[]
+                    const int cmd = uni(xch_cmd[0]);
+                    if (cmd & 4) break;
+                    xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
+                    if (cmd & 1) {
+                        const double part = wave_sum(data_F(uni(xch_res[2]), se[lane], 0));  // wave 1 owns no slab words
+                        const double q = quad_F();
+                        if (lane == 0) { xch_res[0] = part; xch_res[1] = q; }
+                    }
+                    if (cmd & 2) {
+                        eval_DF();
+                        if (lane < n) xch_gv[lane] = gv[0];
+                    }
+                    __syncthreads();  // results posted
+                }
+                return;
+            }
+        }
+        // wave 0 of the two-wave form: f and/or df at xt, shared with wave 1
+        auto eval_split = [&](bool do_f, bool do_g, double &f_out) __attribute__((always_inline)) {
+            double m = 0.0, ssum = 0.0, e_lane = 0.0;
+            int icnt = 1;
+            if (do_f) head_F(m, icnt, ssum, e_lane);
+            if (lane < n) xch_xt[lane] = xt[0];
+            if (lane == 0) { xch_cmd[0] = (do_f ? 1 : 0) | (do_g ? 2 : 0); xch_res[2] = m; }
+            __syncthreads();
+            double lse = 0.0, part = 0.0;
+            if (do_f) {
+                lse = lse_F(m, icnt, ssum);
+                part = wave_sum(data_F(m, e_lane, NdL));
+            }
+            __syncthreads();
+            if (do_f) {
+                const double part_all = part + uni(xch_res[0]);
+                const double q = uni(xch_res[1]);
+                f_out = 0.5 * q - (part_all - Ndoc * lse);
+            }
+            if (do_g) gv[0] = (lane < n) ? xch_gv[lane] : 0.0;
+        };
+
+        auto dot = [&](const double (&a)[VPL], const double (&b)[VPL]) __attribute__((always_inline)) -> double {
             double t = 0.0;
 #pragma unroll
             for (int r = 0; r < VPL; ++r) t += a[r] * b[r];
             return wave_sum(t);
         };
-        auto maxabs = [&](const double (&a)[VPL]) -> double {
+        auto maxabs = [&](const double (&a)[VPL]) __attribute__((always_inline)) -> double {
             double t = 0.0;
 #pragma unroll
             for (int r = 0; r < VPL; ++r) t = nanmax(t, fabs(a[r]));
             return wave_nanmax(t);
         };
         // out_i = sum_j H[j][i] * vec_j  (H symmetric; row j is contiguous across lanes)
-        auto matvecH = [&](const double (&vec)[VPL], double (&out)[VPL]) {
+        auto matvecH = [&](const double (&vec)[VPL], double (&out)[VPL]) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < VPL; ++r)
                 if (lane + WAVE * r < n) sv[lane + WAVE * r] = vec[r];
-            __syncthreads();
+            STM_WAVE_SYNC_MEM();
 #pragma unroll
             for (int r = 0; r < VPL; ++r) {
                 const int i = lane + WAVE * r;
@@ -447,7 +563,7 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                     for (int j = 0; j < n; ++j) t += Hs[(size_t)j * n + i] * sv[j];
                 out[r] = t;
             }
-            __syncthreads();
+            STM_WAVE_SYNC();
         };
 
         // ---- scipy _minimize_bfgs state (optimize/_optimize.py:1328-1502)
@@ -457,7 +573,8 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
         int k = 0, status = 0;
         bool H_ident = true;
         // line-search shared
-        ud phi0, old_phi0, derphi0;
+        ud phi0, old_phi0, derphi0, Lb;
+        const ud sig_lmax = P.sig_bound;
         // DCSRCH state (optimize/_dcsrch.py)
         ud stx, fx, gx, sty, fy, gy, stmin, stmax, width, width1, finit, ginit, gtest;
         int stage = 1, w1_calls = 0;
@@ -477,8 +594,10 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
 
         if (P.debug_flags & 1) st = S_FINISH;
         long guard = 0;
+        if (P.prof) t_init = (long long)__builtin_readcyclecounter() - t_begin;
         while (st != S_FINISH) {
             if (++guard > 400000L) { status = 1000 + st; break; }
+            const long long tq0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
             if (want_eval) {
                 // xk + alpha * pk (separate multiply and add, like numpy)
                 double xn[VPL];
@@ -494,16 +613,31 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                     for (int r = 0; r < VPL; ++r) xt[r] = xn[r];
                     have_x = true; f_ok = false; g_ok = false;
                 }
-                if (need_f) {
-                    if (!f_ok) { cache_f = eval_F(); f_ok = true; ++nfev; }
-                    fval = cache_f;
-                }
-                if (need_g) {
-                    if (!g_ok) { eval_DF(); g_ok = true; ++njev; }
-                    dval = dot(gv, p);
+                if (NW == 2) {
+                    const bool do_f = need_f && !f_ok, do_g = need_g && !g_ok;
+                    if (do_f || do_g) {
+                        double fnew = 0.0;
+                        eval_split(do_f, do_g, fnew);
+                        if (do_f) { cache_f = fnew; f_ok = true; ++nfev; }
+                        if (do_g) { g_ok = true; ++njev; }
+                    }
+                    if (need_f) fval = cache_f;
+                    if (need_g) dval = dot(gv, p);
+                } else {
+                    if (need_f) {
+                        if (!f_ok) { cache_f = eval_F(); f_ok = true; ++nfev; }
+                        fval = cache_f;
+                    }
+                    if (need_g) {
+                        if (!g_ok) { eval_DF(); g_ok = true; ++njev; }
+                        dval = dot(gv, p);
+                    }
                 }
                 want_eval = false;
             }
+            const long long tq1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            const bool was_upd = st == S_ACCEPT2;
+            const int st_in = st;
             switch (st) {
             case S_INIT_DONE: {
                 old_fval = fval;
@@ -525,6 +659,7 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                     for (int r = 0; r < VPL; ++r) p[r] = -t[r];
                 }
                 derphi0 = dot(g, p);
+                Lb = (sig_lmax + Ndoc) * dot(p, p);
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
                 st = S_W1_START;
@@ -564,21 +699,22 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                 }
                 if (task == 2) { st = S_W2_START; break; }
                 {
+                    // modified function (psi) in stage 1, plain one otherwise: selects, not branches
                     const bool mod = (stage == 1 && f <= fx && f > ftest);
-                    double fm = f, fxm = fx, fym = fy, gm = gd, gxm = gx, gym = gy;
-                    if (mod) {
-                        fm = f - stp * gtest; fxm = fx - stx * gtest; fym = fy - sty * gtest;
-                        gm = gd - gtest; gxm = gx - gtest; gym = gy - gtest;
-                    }
-                    double l_stx = stx, l_sty = sty;
-                    dcstep(l_stx, fxm, gxm, l_sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
-                    stx = l_stx; sty = l_sty;
-                    if (mod) {
-                        fx = fxm + stx * gtest; fy = fym + sty * gtest;
-                        gx = gxm + gtest; gy = gym + gtest;
-                    } else {
-                        fx = fxm; fy = fym; gx = gxm; gy = gym;
-                    }
+                    const double gt = mod ? (double)gtest : 0.0;
+                    DcStep in;
+                    in.stx = stx; in.sty = sty; in.stp = stp; in.brackt = brackt;
+                    in.fx = mod ? fx - stx * gt : (double)fx;
+                    in.fy = mod ? fy - sty * gt : (double)fy;
+                    in.dx = mod ? gx - gt : (double)gx;
+                    in.dy = mod ? gy - gt : (double)gy;
+                    const double fm = mod ? f - stp * gt : f, gm = mod ? gd - gt : gd;
+                    const DcStep out = dcstep(in, fm, gm, stmin, stmax);
+                    stx = out.stx; sty = out.sty; stp = out.stp; brackt = out.brackt;
+                    fx = mod ? out.fx + out.stx * gt : out.fx;
+                    fy = mod ? out.fy + out.sty * gt : out.fy;
+                    gx = mod ? out.dx + gt : out.dx;
+                    gy = mod ? out.dy + gt : out.dy;
                 }
                 if (brackt) {
                     if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
@@ -597,6 +733,17 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                     (brackt && stmax - stmin <= xtol * stmax))
                     stp = stx;
                 if (!finite_d(stp) || w1_calls >= 100) { st = S_W2_START; break; }
+                // Outcome-preserving shortcut for the tail of a failing search.  Once the minimiser is
+                // bracketed every later trial step lies in [0, smax], smax = max(stx, sty) (the interval
+                // only shrinks; an out-of-range step is replaced by stx).  phi'(s) = df(x + s p).p has
+                // |phi'(s) - phi'(0)| <= s (lambda_max(siginv) + N_d) |p|^2 =: s Lb  (the Jacobian of
+                // df is siginv + N_d (diag(theta) - theta theta^T), eigenvalues <= lambda_max + N_d).
+                // DCSRCH reports convergence only if |phi'(s)| <= 0.9 |phi'(0)|, impossible while
+                // smax Lb < 0.1 |phi'(0)| (tested with a 2x margin for the rounding of phi').  What
+                // remains is ~60 evaluations inside rounding noise that can only end in a WARNING or
+                // the 100-call cap, i.e. alpha = None and the hand-over to wolfe2, whose start does
+                // not depend on DCSRCH's final state.
+                if (brackt && py_max2(stx, sty) * Lb <= 0.05 * -derphi0) { st = S_W2_START; break; }
                 alpha = stp; need_f = true; need_g = true; want_eval = true;
                 st = S_W1_ITER;
             } break;
@@ -653,6 +800,10 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                 st = S_W2_TOP;
             } break;
             case S_ZOOM_TOP: {  // _zoom (optimize/_linesearch.py:532-621)
+                // same bound as in S_W1_ITER: every later a_j lies between a_lo and a_hi, and zoom accepts
+                // only when |phi'(a_j)| <= 0.9 |phi'(0)|; if that is out of reach the remaining iterations
+                // can only exhaust maxiter = 10 -> _LineSearchError -> status 2 with x unchanged
+                if (py_max2(a_lo, a_hi) * Lb <= 0.05 * -derphi0 && a_lo >= 0 && a_hi >= 0) { status = 2; st = S_FINISH; break; }
                 const double dalpha = a_hi - a_lo;
                 double a, b;
                 if (dalpha < 0) { a = a_hi; b = a_lo; } else { a = a_lo; b = a_hi; }
@@ -738,7 +889,7 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
                     if (lane + WAVE * r < n) { sv[lane + WAVE * r] = s[r]; sw[lane + WAVE * r] = w[r]; }
-                __syncthreads();
+                STM_WAVE_SYNC();
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) {
                     const int j = lane + WAVE * r;
@@ -751,12 +902,22 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
                         }
                     }
                 }
-                __syncthreads();
+                STM_WAVE_SYNC_MEM();
                 H_ident = false;
                 st = S_OUTER_TOP;
             } break;
             default: st = S_FINISH; break;
             }
+            if (P.prof) {
+                const long long tq2 = (long long)__builtin_readcyclecounter();
+                t_eval += tq1 - tq0;
+                if (was_upd) t_upd += tq2 - tq1; else t_sm += tq2 - tq1;
+                if (lane == 0) { P.prof[doc * 40 + 8 + st_in] += tq2 - tq1; P.prof[doc * 40 + 24 + st_in] += 1; }
+            }
+        }
+        if (NW == 2) {  // release the evaluation server
+            if (lane == 0) xch_cmd[0] = 4;
+            __syncthreads();
         }
         if (status == 0) {
             if (k >= maxiter) status = 1;
@@ -773,6 +934,9 @@ __global__ __launch_bounds__(64, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver
             if (i < n) P.eta[doc * n + i] = x[r];
         }
         // uniform stores (every lane writes the same word)
+        if (P.prof && lane == 0) {
+            P.prof[doc * 40 + 0] = t_init; P.prof[doc * 40 + 1] = t_eval; P.prof[doc * 40 + 2] = t_sm; P.prof[doc * 40 + 3] = t_upd;
+        }
         if (P.status) P.status[doc] = status;
         if (P.nit) P.nit[doc] = k;
         if (P.nfev) P.nfev[doc] = nfev;

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Per-document shader-clock breakdown of the solver kernel (STM_DEBUG_PROF=1): init / evaluations /
+state machine / BFGS update, averaged over a 20k-document corpus at EM iteration 0 and 1."""
+import ctypes as C, os, sys
+os.environ["STM_DEBUG_PROF"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from strutopy_amd import STM, _lib
+from strutopy_amd.corpus import synthetic_corpus
+syn = synthetic_corpus(20000, 10000, 50, n_words=150, seed=12345)
+m = STM(documents=syn.corpus, dictionary=None, content=False, K=50, X=syn.X, kappa_interactions=False, max_em_iter=2,
+        sigma_prior=0, convergence_threshold=1e-9, init_type="random")
+for it in range(2):
+    m._em_iteration_resident()
+    out = np.zeros((m.N, 40), dtype=np.int64)
+    _lib.check(_lib.lib().stm_debug_get_prof(m._engine._h, out.ctypes.data_as(C.POINTER(C.c_longlong))))
+    d = m.solver_diagnostics()
+    tot = out[:, :4].sum(1)
+    print(f"it{it}: cycles/doc init {out[:,0].mean():.0f} eval {out[:,1].mean():.0f} sm {out[:,2].mean():.0f} upd {out[:,3].mean():.0f} total {tot.mean():.0f}"
+          f" | nfev {d['nfev'].mean():.1f} njev {d['njev'].mean():.1f} nit {d['nit'].mean():.2f} | per eval {out[:,1].mean()/d['nfev'].mean():.0f} sm/eval {out[:,2].mean()/d['nfev'].mean():.0f}"
+          f" kernel {m.timings[-1]['kernels']}")
+    names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
+             "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "ZOOM_NEXT", "ACCEPT", "ACCEPT2", "FINISH"]
+    for i, nm in enumerate(names):
+        c, v = out[:, 8 + i].mean(), out[:, 24 + i].mean()
+        if v > 0:
+            print(f"      {nm:12s} visits/doc {v:6.2f}  cycles/visit {c / v:8.0f}  cycles/doc {c:9.0f}")
