@@ -169,7 +169,8 @@ static int plan_solver(stm_handle *h) {
     const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
     const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
     h->KP = KP;
-    auto lds_of = [&](int nd) { return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double); };
+    const size_t h_lds = h->nw == 2 ? (size_t)h->n * h->n * sizeof(double) : 0;  // BFGS matrix in LDS (two-wave form)
+    auto lds_of = [&](int nd) { return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double) + h_lds; };
     auto per_cu = [&](int nd) -> int {
         const size_t b = ((lds_of(nd) + LDS_STATIC + 511) / 512) * 512;
         if (mode == 2 || b > LDS_PER_CU) return 0;
@@ -348,7 +349,13 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     const size_t budget = (size_t)env_int("STM_SLAB_BUDGET_MB", 24576) << 20;
     h->chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(h->N, 1), (int64_t)(budget / std::max<size_t>(n * n * sizeof(double), 8))));
     h->nrep = env_int("STM_SIGMA_REPLICAS", 256);
-    if (int rc = dalloc(&h->d_slab_H, (size_t)h->chunk * n * n)) return rc;
+    {   // documents that keep their BFGS matrix in the global slab: all of them for the one-wave forms,
+        // only the too-long-for-LDS groups for the two-wave form
+        int64_t need = 0;
+        for (const auto &gr : h->groups)
+            if (h->nw == 1 || gr.global) need = std::max<int64_t>(need, std::min<int64_t>(gr.count, h->chunk));
+        if (int rc = dalloc(&h->d_slab_H, (size_t)std::max<int64_t>(need, 1) * n * n)) return rc;
+    }
     if (int rc = dalloc(&h->d_sigma_part, (size_t)h->nrep * n * n)) return rc;
     HIP_TRY(hipMemsetAsync(h->d_eta, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_mu, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
     constexpr int KR = (KREG > 0) ? KREG : 2;
     static_assert(KREG % 2 == 0 && KREG <= KMAX, "KREG must be even and <= 64*VPL");
     static_assert(NW == 1 || (NW == 2 && VPL == 1 && KREG > 0 && !GLOBAL_SLAB), "two-wave form: VPL = 1, registers + LDS");
-    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld]
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld] | H[n][n] (NW = 2)
     __shared__ __attribute__((aligned(16))) double se[KMAX + 2];  // exp(eta~ - m), broadcast to every lane
     __shared__ double sv[KMAX + 1];  // vector broadcast (matvec operand / s)
     __shared__ double sw[KMAX + 1];  // vector broadcast (w = H y)
@@ -220,7 +220,9 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
     double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
     double *crow = slab + (size_t)KP * ld;  // counts of the slab words
     double *wrow = crow + ld;               // counts / colsum(beta_d)
-    double *Hs = P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
+    // BFGS inverse-Hessian estimate (n x n): in LDS behind the slab for the two-wave form (its slab is
+    // small), in a private global slab otherwise
+    double *Hs = (NW == 2) ? dyn_lds + (size_t)(KP + 2) * ld : P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
     const double *S = P.siginv;
     const bool sdiag = P.siginv_diag != 0;
 
