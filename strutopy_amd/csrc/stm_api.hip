@@ -503,6 +503,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     pp.hess_out = h->d_hess; pp.chol_out = h->d_chol; pp.nu_out = h->d_nu;
     pp.phi_doc = h->phi_doc; pp.phi_out = h->d_phi;
     pp.debug_flags = env_int("STM_POST_DEBUG", 0);
+    pp.prof = h->d_prof;
 
     const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));

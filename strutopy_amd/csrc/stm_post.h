@@ -54,6 +54,7 @@ struct PostParams {
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
     int MLD;               // leading dimension of the LDS matrix (odd, >= n)
+    long long *prof;       // optional [N][40] (shared with the solver's): [32..39] post-kernel phase cycles
 };
 
 constexpr int PT = 64;    // topics padded to 64 (K <= 64 in this kernel)
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
         double *bssT = P.beta_ssT + (size_t)asp * (size_t)P.V * K;
         const bool dump_phi = P.phi_out && doc == P.phi_doc;
+        long long tp[8];
+        tp[0] = P.prof ? (long long)__builtin_readcyclecounter() : 0;
 
         // ---- eta~, theta (unshifted softmax, stm.py:547-549), stable softmax, exp(eta~)
         const double eta_i = isn ? P.eta[doc * n + lane] : 0.0;  // lane K-1 holds the appended 0
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         for (int q = lane; q < PT * TLD; q += WAVE) T[q] = 0.0;
         __syncthreads();
 
+        if (P.prof) tp[1] = (long long)__builtin_readcyclecounter();
         double csum = 0.0, ll = 0.0, rowc = 0.0;
         bool bad = false;
         v4d acc[NT];
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
             }
             __syncthreads();
         }
+        if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         }
         __syncthreads();
 
+        if (P.prof) tp[3] = (long long)__builtin_readcyclecounter();
         // ---- PD handling.  diagA: current diagonal of A (lane i); off-diagonals of A are read
         // from the upper triangle of M, which Cholesky never writes.
         double diagA = isn ? M[(size_t)lane * MLD + lane] : 1.0;
@@ -258,13 +264,24 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 if (isn && lane >= j) {
                     t = (lane == j) ? diagA : M[(size_t)j * MLD + lane];
                     const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD;
-                    for (int l = 0; l < j; ++l) t -= ri[l] * rj[l];
+                    // four independent partial sums: the LDS reads of several l are in flight together
+                    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+                    int l = 0;
+                    for (; l + 3 < j; l += 4) {
+                        t0 = fma(ri[l], rj[l], t0);
+                        t1 = fma(ri[l + 1], rj[l + 1], t1);
+                        t2 = fma(ri[l + 2], rj[l + 2], t2);
+                        t3 = fma(ri[l + 3], rj[l + 3], t3);
+                    }
+                    for (; l < j; ++l) t0 = fma(ri[l], rj[l], t0);
+                    t -= (t0 + t1) + (t2 + t3);
                 }
                 const double d = lane_bcast(t, j);
                 if (!(d > 0.0)) { ok = false; break; }
                 const double ljj = sqrt(d);
+                const double rjj = 1.0 / ljj;   // LAPACK dpotf2 scales the column by the reciprocal as well
                 if (lane == j) Ldiag = ljj;
-                if (isn && lane > j) M[(size_t)lane * MLD + j] = t / ljj;
+                if (isn && lane > j) M[(size_t)lane * MLD + j] = t * rjj;
                 __syncthreads();
             }
             __syncthreads();
@@ -330,6 +347,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 }
         }
 
+        if (P.prof) tp[4] = (long long)__builtin_readcyclecounter();
         // ---- bound (stm.py:1068-1101)
         const double det = wave_sum(isn ? log(Ldiag) : 0.0);
         double q = 0.0;
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         P.bound[doc] = ll + (-det) - 0.5 * q - P.sigmaentropy;  // uniform store
         if (P.debug_flags & 4) continue;
 
+        if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066)
         const double Rdiag = 1.0 / Ldiag;
         srd[lane] = isn ? Rdiag : 0.0;
@@ -359,19 +378,30 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
             for (int i = n - 2; i >= 0; --i) {
                 double t = 0.0;
                 if (isn && lane > i) {
-                    t = -(M[(size_t)lane * MLD + i] * Rdiag);  // the l == lane term
-                    for (int l = i + 1; l < n - 1; ++l) {
-                        const double rlc = (l < lane) ? M[(size_t)l * MLD + lane] : 0.0;
-                        t -= M[(size_t)l * MLD + i] * rlc;
+                    // sum_{l=i+1..lane} L[l][i] R[l][lane]: rows below `lane` contribute nothing (R is upper
+                    // triangular) -- loaded unconditionally and masked, so the reads of several l overlap
+                    const double *ci = M + i, *cl = M + lane;
+                    double t0 = M[(size_t)lane * MLD + i] * Rdiag, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // l == lane term
+                    int l = i + 1;
+                    for (; l + 3 < n - 1; l += 4) {
+                        const double r0 = cl[(size_t)l * MLD], r1 = cl[(size_t)(l + 1) * MLD];
+                        const double r2 = cl[(size_t)(l + 2) * MLD], r3 = cl[(size_t)(l + 3) * MLD];
+                        t0 = fma(ci[(size_t)l * MLD], (l < lane) ? r0 : 0.0, t0);
+                        t1 = fma(ci[(size_t)(l + 1) * MLD], (l + 1 < lane) ? r1 : 0.0, t1);
+                        t2 = fma(ci[(size_t)(l + 2) * MLD], (l + 2 < lane) ? r2 : 0.0, t2);
+                        t3 = fma(ci[(size_t)(l + 3) * MLD], (l + 3 < lane) ? r3 : 0.0, t3);
                     }
+                    for (; l < n - 1; ++l) t0 = fma(ci[(size_t)l * MLD], (l < lane) ? cl[(size_t)l * MLD] : 0.0, t0);
+                    t = -((t0 + t1) + (t2 + t3));
                 }
-                const double lii = lane_bcast(Ldiag, i);
-                __syncthreads();
-                if (isn && lane > i) M[(size_t)i * MLD + lane] = t / lii;
+                const double rii = lane_bcast(Rdiag, i);   // 1 / L[i][i]
+                // row i of R is not read during step i: no barrier needed before the store
+                if (isn && lane > i) M[(size_t)i * MLD + lane] = t * rii;
                 __syncthreads();
             }
         }
         __syncthreads();
+        if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
         // nu = R R^T on the matrix cores, accumulated straight into the workgroup's running sum
         // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq], zero below the diagonal
         v4d nud[DUMP ? NT : 1];
@@ -417,6 +447,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     }
                     acc_nu[t] += nud[t];
                 }
+        }
+        if (P.prof && lane == 0) {
+            tp[7] = (long long)__builtin_readcyclecounter();
+            for (int q = 0; q < 7; ++q) P.prof[doc * 40 + 32 + q] = tp[q + 1] - tp[q];
         }
     }
 

@@ -21,6 +21,8 @@ for it in range(2):
           f" kernel {m.timings[-1]['kernels']}")
     names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
              "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "ZOOM_NEXT", "ACCEPT", "ACCEPT2", "FINISH"]
+    pn = ["prologue", "word tiles", "sums", "H assembly", "Cholesky ladder", "bound", "inverse R", "nu MFMA"]
+    print("   post kernel cycles/doc: " + ", ".join(f"{pn[q]} {out[:, 32 + q].mean():.0f}" for q in range(7)) + f", total {out[:, 32:39].sum(1).mean():.0f}")
     for i, nm in enumerate(names):
         c, v = out[:, 8 + i].mean(), out[:, 24 + i].mean()
         if v > 0:
