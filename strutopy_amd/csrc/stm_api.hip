@@ -43,6 +43,14 @@ int dalloc(T **p, size_t count) {
     if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     return STM_OK;
 }
+// grow-only allocation for buffers reused on every EM iteration (no free / malloc in the loop)
+template <class T>
+int ensure(T **p, size_t *cur, size_t count) {
+    if (*p && *cur >= count) return STM_OK;
+    if (int rc = dalloc(p, count)) return rc;
+    *cur = count;
+    return STM_OK;
+}
 template <class T>
 void dfree(T *&p) {
     if (p) (void)hipFree(p);
@@ -109,6 +117,7 @@ struct stm_handle {
     // M-step
     int p = 0;
     double *d_X = nullptr, *d_mom = nullptr, *d_gamma = nullptr, *d_cov = nullptr;
+    size_t mom_len = 0, cov_len = 0, gamma_len = 0, phi_len = 0;
     // comm
     void *comm = nullptr;
     int rank = 0, nranks = 1;
@@ -480,7 +489,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     h->phi_doc = h->N - 1;
     if (h->N > 0) {
         const size_t nd = (size_t)(h->h_indptr[h->N] - h->h_indptr[h->N - 1]);
-        if (int rc = dalloc(&h->d_phi, (size_t)K * nd)) return rc;
+        if (int rc = ensure(&h->d_phi, &h->phi_len, (size_t)K * nd)) return rc;
     }
 
     stm::SolverParams sp{};

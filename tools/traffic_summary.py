@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, separate passes, KB) -> HBM bytes per launch per kernel.
+"""FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, separate passes, KB) -> HBM bytes per E-step per kernel
+(summed over the kernel's dispatches of a one-step bench run: the solver is launched once per LDS
+occupancy class, everything else once).
 
 MI355X_MICROARCH.md (HBM section): hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; on gfx950 FETCH_SIZE
 under-reports coalesced reads by a pattern-dependent factor (exactly 2x for 16-B/lane streams) and has to
@@ -18,23 +20,23 @@ def per_kernel(path):
         k = k.split("<")[0]
         agg[k] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
-    return {k: agg[k] / max(len(cnt[k]), 1) for k in agg}
+    return {k: agg[k] for k in agg}, {k: len(cnt[k]) for k in agg}
 
 
-fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+(fetch, ndisp), (write, _) = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 100000
 K = int(sys.argv[5]) if len(sys.argv) > 5 else 50
 known = 2.0 * N * (K - 1) * 8
 cal = known / (fetch.get("stm::covariance_kernel", 0.0) * 1024) if fetch.get("stm::covariance_kernel") else None
-out = {"_units": "bytes per launch", "_fetch_calibration": cal,
+out = {"_units": "bytes per E-step (all dispatches of the kernel in one EM iteration)", "_fetch_calibration": cal,
        "_note": "FETCH_SIZE*1024*calibration + WRITE_SIZE*1024; calibration = known bytes of covariance_kernel / its FETCH_SIZE"}
 for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, 0.0) * 1024 * (cal or 1.0)
     w = write.get(k, 0.0) * 1024
     out[k] = f + w
-    out[k + "#raw"] = {"FETCH_SIZE_KB": fetch.get(k, 0.0), "WRITE_SIZE_KB": write.get(k, 0.0)}
+    out[k + "#raw"] = {"FETCH_SIZE_KB": fetch.get(k, 0.0), "WRITE_SIZE_KB": write.get(k, 0.0), "dispatches": ndisp.get(k, 0)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
     if not k.startswith("_") and not k.endswith("#raw"):
-        print(f"{k:45s} {v / 1e6:12.2f} MB/launch   raw {out[k + '#raw']}")
+        print(f"{k:45s} {v / 1e6:12.2f} MB/E-step   raw {out[k + '#raw']}")
 print("fetch calibration factor:", cal)
