@@ -39,6 +39,8 @@ extern "C" {
 typedef struct stm_handle stm_handle;
 
 /* ---- lifetime --------------------------------------------------------- */
+/* number of usable GPUs (0 and STM_ERR_NO_DEVICE when there is none) */
+int stm_device_count(int *count);
 int stm_create(stm_handle **out, int device_ordinal);
 void stm_destroy(stm_handle *h);
 const char *stm_last_error(void);

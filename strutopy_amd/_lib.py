@@ -35,6 +35,7 @@ class EstepArgs(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/stm_estep.h declares
 SIGNATURES = {
+    "stm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "stm_create": (C.c_int, [C.POINTER(_h), C.c_int]),
     "stm_destroy": (None, [_h]),
     "stm_last_error": (C.c_char_p, []),

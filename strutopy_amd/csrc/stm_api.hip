@@ -223,6 +223,15 @@ extern "C" {
 
 const char *stm_last_error(void) { return g_err.c_str(); }
 
+int stm_device_count(int *count) {
+    if (!count) return fail(STM_ERR_INVALID, "stm_device_count: count is NULL");
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    *count = (e == hipSuccess && cnt > 0) ? cnt : 0;
+    if (*count == 0) return fail(STM_ERR_NO_DEVICE, "no HIP device available (the E-step has no CPU fallback)");
+    return STM_OK;
+}
+
 int stm_create(stm_handle **out, int device_ordinal) {
     if (!out) return fail(STM_ERR_INVALID, "stm_create: out is NULL");
     *out = nullptr;

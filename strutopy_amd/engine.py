@@ -12,6 +12,13 @@ from . import _lib
 from ._lib import check, dptr, f64, iptr, lptr
 
 
+def device_count():
+    """Usable GPUs (raises StmError when there is none -- there is no CPU fallback)."""
+    n = C.c_int(0)
+    check(_lib.lib().stm_device_count(C.byref(n)))
+    return n.value
+
+
 class HipEstepEngine:
     def __init__(self, device=0):
         self._L = _lib.lib()
