@@ -63,6 +63,11 @@ constexpr int TLD = 18;   // leading dimension of T: MFMA fragment reads are con
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// LDS hand-off between lanes of the (single) wave of a workgroup: the LDS executes a wave's operations in
+// order, so only the compiler must not reorder them -- unlike __syncthreads() this does not drain the
+// global loads that are deliberately kept in flight across the hand-off
+#define STM_POST_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 #ifndef STM_POST_WPE
 #define STM_POST_WPE 2   // waves per SIMD the post kernel is register-budgeted for
 #endif
@@ -87,10 +92,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     double *sdv = vec + 2 * PT;   // eta - mu broadcast (dense siginv only)
     double *srow = vec + 3 * PT;  // rowsum(c') per topic
     double *srd = vec + 4 * PT;   // 1 / diag(L)
-    double *wsq = vec + 5 * PT;   // per word of the tile: sqrt(c)
-    double *wS = wsq + TW;        //                       colsum S
-    double *wr = wS + TW;         //                       1 / S
-    double *ww = wr + TW;         //                       sqrt(c) / S
+    double *wpar = vec + 5 * PT;  // per word of the tile: { sqrt(c), colsum S, 1 / S, sqrt(c) / S }
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
     const bool isn = lane < n, isk = lane < K;
@@ -122,12 +124,12 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         const double es = isk ? exp(eta_i - m) : 0.0;
         const double ssum = wave_sum(es);
         const double ths = es / ssum;
-        __syncthreads();  // the previous document's readers of M / vec are done
+        STM_POST_SYNC();  // the previous document's readers of M / vec are done
         sex[lane] = ex;
         sth[lane] = isk ? ths : 0.0;
         // topic rows K..63 of T stay zero for the whole document
         for (int q = lane; q < PT * TLD; q += WAVE) T[q] = 0.0;
-        __syncthreads();
+        STM_POST_SYNC();
 
         if (P.prof) tp[1] = (long long)__builtin_readcyclecounter();
         double csum = 0.0, ll = 0.0, rowc = 0.0;
@@ -137,27 +139,45 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
         const int kc = (K + 3) >> 2;  // topics per quarter in step 2
 
-        for (int t0 = 0; t0 < Nd; t0 += TW) {
-            const int nw = Nd - t0 < TW ? Nd - t0 : TW;
-            const int my_idx = (lane < nw) ? P.indices[p0 + t0 + lane] : 0;
-            const double my_c = (lane < nw) ? P.counts[p0 + t0 + lane] : 0.0;
-            // -- 1. gather: 16 coalesced rows, transposed into T[topic][word]
-            double g[TW];
+        // Software pipeline over the tiles: while tile t is reduced / scattered / multiplied, the beta rows
+        // of tile t+1 are already in flight (into the registers the LDS transpose of tile t has just
+        // released) and the word ids / counts of tile t+2 are being fetched.
+        auto load_ids = [&](int t0, int &idx, double &c) __attribute__((always_inline)) {
+            const bool in = t0 + lane < Nd && lane < TW;
+            idx = in ? P.indices[p0 + t0 + lane] : 0;
+            c = in ? P.counts[p0 + t0 + lane] : 0.0;
+        };
+        double g[TW];
+        auto load_rows = [&](int t0, int idx_l) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < TW; ++j) {
-                const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                g[j] = (isk && j < nw) ? bT[(size_t)idx * K + lane] : 0.0;
+                const int idx = __builtin_amdgcn_readlane(idx_l, j);
+                g[j] = (isk && t0 + j < Nd) ? bT[(size_t)idx * K + lane] : 0.0;
             }
+        };
+        int my_idx, idx1;
+        double my_c, c1;
+        load_ids(0, my_idx, my_c);
+        load_ids(TW, idx1, c1);
+        load_rows(0, my_idx);
+        for (int t0 = 0; t0 < Nd; t0 += TW) {
+            const int nw = Nd - t0 < TW ? Nd - t0 : TW;
+            // -- 1. the tile's 16 coalesced rows (issued one tile ago), transposed into T[topic][word]
             if (isk) {
                 double2 *row = reinterpret_cast<double2 *>(T + (size_t)lane * TLD);
 #pragma unroll
                 for (int j = 0; j < TW; j += 2) row[j >> 1] = make_double2(g[j], g[j + 1]);
             }
-            __syncthreads();
+            int idx2;
+            double c2;
+            if (t0 + TW < Nd) load_rows(t0 + TW, idx1);
+            load_ids(t0 + 2 * TW, idx2, c2);
+            STM_POST_SYNC();
             // -- 2. per-word sums, lane = (word fr, topic quarter fq)
             {
                 double Sp = 0.0, Lp = 0.0;
                 const int k0 = fq * kc;
+#pragma unroll 4
                 for (int kk = 0; kk < kc; ++kk) {
                     const int k = k0 + kk;
                     const double a = T[(size_t)k * TLD + fr] * sex[k];
@@ -171,33 +191,47 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     const double sq = sqrt(c);
                     ll += log_pos(Lp) * c;
                     csum += c;
-                    wsq[lane] = sq;
-                    wS[lane] = Sp;
-                    wr[lane] = 1.0 / Sp;
-                    ww[lane] = sq / Sp;   // update_z: sqrt(c) / colsum, stm.py:1115
+                    double *wp = wpar + 4 * lane;
+                    wp[0] = sq;
+                    wp[1] = Sp;
+                    wp[2] = 1.0 / Sp;
+                    wp[3] = sq / Sp;      // update_z: sqrt(c) / colsum, stm.py:1115
                 }
             }
-            __syncthreads();
+            STM_POST_SYNC();
             // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
             if (isk) {
                 double *trow = T + (size_t)lane * TLD;
-                for (int j = 0; j < nw; ++j) {
-                    const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                    const double sq = wsq[j], Sj = wS[j], rj = wr[j], wj = ww[j];
-                    const double a = trow[j] * ex;
-                    // b = a*sqrt(c)/S (stm.py:1001): quotient by the shared divisor from its reciprocal
-                    const double num = a * sq;
-                    const double q0 = num * rj;
-                    const double b = fma(fma(-q0, Sj, num), rj, q0);
-                    const double phi = a * wj * sq;   // stm.py:1115-1116
-                    bad |= !(phi >= 0.0);
-                    rowc += b * sq;                   // rowsum(c'), c' = b*sqrt(c), stm.py:1002,1011
-                    trow[j] = b;
-                    if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, phi);  // stm.py:588
-                    if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = phi;
+                // four words per round: their LDS reads are issued together, the tail is masked
+                for (int j0 = 0; j0 < nw; j0 += 4) {
+                    double tv[4], sq[4], Sj[4], rj[4], wj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u < nw ? j0 + u : nw - 1;
+                        tv[u] = trow[j];
+                        sq[u] = wpar[4 * j]; Sj[u] = wpar[4 * j + 1]; rj[u] = wpar[4 * j + 2]; wj[u] = wpar[4 * j + 3];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        if (j < nw) {   // uniform
+                            const int idx = __builtin_amdgcn_readlane(my_idx, j);
+                            const double a = tv[u] * ex;
+                            // b = a*sqrt(c)/S (stm.py:1001): quotient by the shared divisor from its reciprocal
+                            const double num = a * sq[u];
+                            const double q0 = num * rj[u];
+                            const double b = fma(fma(-q0, Sj[u], num), rj[u], q0);
+                            const double phi = a * wj[u] * sq[u];   // stm.py:1115-1116
+                            bad |= !(phi >= 0.0);
+                            rowc += b * sq[u];                  // rowsum(c'), c' = b*sqrt(c), stm.py:1002,1011
+                            trow[j] = b;
+                            if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, phi);  // stm.py:588
+                            if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = phi;
+                        }
+                    }
                 }
             }
-            __syncthreads();
+            STM_POST_SYNC();
             // -- 4. b b^T on the matrix cores, upper block triangle
             if (!(P.debug_flags & 2)) {
 #pragma unroll
@@ -213,7 +247,8 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
                 }
             }
-            __syncthreads();
+            STM_POST_SYNC();
+            my_idx = idx1; my_c = c1; idx1 = idx2; c1 = c2;
         }
         if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
@@ -239,7 +274,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                         }
                     }
         }
-        __syncthreads();
+        STM_POST_SYNC();
         if (isn) {
             double *mi = M + (size_t)lane * MLD;
             const double thi = sth[lane];
@@ -250,7 +285,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 mi[j] = h + sij;
             }
         }
-        __syncthreads();
+        STM_POST_SYNC();
 
         if (P.prof) tp[3] = (long long)__builtin_readcyclecounter();
         // ---- PD handling.  diagA: current diagonal of A (lane i); off-diagonals of A are read
@@ -282,9 +317,9 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 const double rjj = 1.0 / ljj;   // LAPACK dpotf2 scales the column by the reciprocal as well
                 if (lane == j) Ldiag = ljj;
                 if (isn && lane > j) M[(size_t)lane * MLD + j] = t * rjj;
-                __syncthreads();
+                STM_POST_SYNC();
             }
-            __syncthreads();
+            STM_POST_SYNC();
             return ok;
         };
         auto make_pd = [&]() {  // stm.py:964-984
@@ -357,7 +392,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 if (isn) q = (d * S[(size_t)lane * n + lane]) * d;
             } else {
                 if (isn) sdv[lane] = d;
-                __syncthreads();
+                STM_POST_SYNC();
                 if (isn) {
                     double t = 0.0;
                     for (int j = 0; j < n; ++j) t += sdv[j] * S[(size_t)j * n + lane];
@@ -397,10 +432,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 const double rii = lane_bcast(Rdiag, i);   // 1 / L[i][i]
                 // row i of R is not read during step i: no barrier needed before the store
                 if (isn && lane > i) M[(size_t)i * MLD + lane] = t * rii;
-                __syncthreads();
+                STM_POST_SYNC();
             }
         }
-        __syncthreads();
+        STM_POST_SYNC();
         if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
         // nu = R R^T on the matrix cores, accumulated straight into the workgroup's running sum
         // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq], zero below the diagonal
