@@ -126,6 +126,14 @@ int stm_mstep_covariance(stm_handle *h, double *cov /* [(K-1)^2] */);
  * beta_ss held on the device */
 int stm_mstep_update_beta(stm_handle *h);
 
+/* ---- held-out likelihood (next-row f-3) -------------------------------- */
+/* eval_heldout(heldout, theta, beta) of src/modules/heldout.py:88-97 against the beta resident on the
+ * handle: doc_ll[d] = sum_w c_w log(theta_d . beta[:, w]) / sum_w c_w for the documents given as CSR
+ * (word ids < V of the handle).  theta [N][K] is a host array; NULL uses the resident theta of the last
+ * E-step (then N must be the corpus' N).  The caller averages doc_ll (np.mean, heldout.py:97). */
+int stm_eval_heldout(stm_handle *h, int64_t N, const int64_t *indptr, const int32_t *indices,
+                     const double *counts, const double *theta, double *doc_ll);
+
 /* ---- multi-GPU: one RCCL all-reduce of the sufficient statistics ------- */
 /* rank 0 calls stm_comm_unique_id and ships the 128 bytes to the other ranks
  * (any side channel); then every rank calls stm_comm_init. */

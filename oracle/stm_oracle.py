@@ -171,3 +171,15 @@ def decompose(H):
     nu = np.zeros((n, n))
     path = lib().stm_oracle_decompose(n, _d(H), _d(L), _d(nu))
     return path, L, nu
+
+
+def eval_heldout_docs(indptr, indices, counts, theta, beta):
+    """Per-document values of the reference's eval_heldout (src/modules/heldout.py:88-97), numpy loop:
+    sum_w c_w log(theta_d @ beta[:, w]) / sum_w c_w; the reference returns np.mean of these."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    out = np.empty(len(indptr) - 1)
+    for i in range(len(out)):
+        sl = slice(indptr[i], indptr[i + 1])
+        word_ll = counts[sl] * np.log(theta[i] @ beta[:, indices[sl]])
+        out[i] = np.sum(word_ll) / np.sum(counts[sl])
+    return out

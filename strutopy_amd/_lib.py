@@ -63,6 +63,7 @@ SIGNATURES = {
     "stm_mstep_set_mu": (C.c_int, [_h, _dp, _dp]),
     "stm_mstep_covariance": (C.c_int, [_h, _dp]),
     "stm_mstep_update_beta": (C.c_int, [_h]),
+    "stm_eval_heldout": (C.c_int, [_h, C.c_int64, _lp, _ip, _dp, _dp, _dp]),
     "stm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "stm_comm_init": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
     "stm_allreduce_suffstats": (C.c_int, [_h, _dp, _dp, C.c_int64]),

@@ -84,6 +84,33 @@ def pack_bow(documents, V=None):
     return PackedCorpus(indptr, indices, counts, int(V))
 
 
+def read_mm(path):
+    """MatrixMarket coordinate file (documents x terms, 1-based, as gensim's MmCorpus writes the
+    reference's src/artifacts/wiki_data/BoW_corpus.mm) -> PackedCorpus, without going through Python
+    lists of tuples (the reference rebuilds np.array(documents[i]) per document per iteration, stm.py:522)."""
+    with open(path) as fh:
+        head = fh.readline()
+        if not head.startswith("%%MatrixMarket matrix coordinate"):
+            raise ValueError("not a MatrixMarket coordinate file")
+        line = fh.readline()
+        while line.startswith("%"):
+            line = fh.readline()
+        n_docs, n_terms, nnz = (int(t) for t in line.split())
+        data = np.loadtxt(fh, ndmin=2)
+    if data.shape[0] != nnz:
+        raise ValueError(f"expected {nnz} entries, found {data.shape[0]}")
+    doc = data[:, 0].astype(np.int64) - 1
+    term = data[:, 1].astype(np.int64) - 1
+    order = np.lexsort((term, doc))
+    doc, term, val = doc[order], term[order], data[order, 2]
+    lens = np.bincount(doc, minlength=n_docs)
+    if n_docs and lens.min() < 1:
+        raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
+    indptr = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(lens, out=indptr[1:])
+    return PackedCorpus(indptr, term.astype(np.int32), val.astype(np.float64), int(n_terms))
+
+
 @dataclass
 class SyntheticCorpus:
     corpus: PackedCorpus

@@ -121,6 +121,30 @@ __global__ void beta_normalise_topics_kernel(const double *bssT, int64_t AV, int
     for (int k = 0; k < K; ++k) betaT[r * K + k] = (s != 0.0) ? bssT[r * K + k] / s : 0.0;
 }
 
+// Held-out per-word log-likelihood of one document per wavefront (reference src/modules/heldout.py:88-97):
+//   doc_ll[d] = sum_w c_w log(theta_d . beta[:, w]) / sum_w c_w      (lane = word, topics in order)
+__global__ __launch_bounds__(64) void heldout_kernel(const int64_t *indptr, const int32_t *indices, const double *counts,
+                                                     const double *betaT, const double *theta, int64_t N, int K,
+                                                     double *doc_ll) {
+    const int64_t d = blockIdx.x;
+    if (d >= N) return;
+    const int lane = threadIdx.x;
+    const int64_t p0 = indptr[d];
+    const int nd = (int)(indptr[d + 1] - p0);
+    const double *th = theta + d * K;
+    double num = 0.0, den = 0.0;
+    for (int v = lane; v < nd; v += 64) {
+        const double *row = betaT + (size_t)indices[p0 + v] * K;
+        double dot = 0.0;
+        for (int k = 0; k < K; ++k) dot += th[k] * row[k];
+        const double c = counts[p0 + v];
+        num += c * log(dot);
+        den += c;
+    }
+    for (int o = 32; o > 0; o >>= 1) { num += __shfl_xor(num, o); den += __shfl_xor(den, o); }
+    if (lane == 0) doc_ll[d] = num / den;
+}
+
 }  // namespace stm
 
 // RCCL binding (resolved lazily with dlopen so a single-GPU run never loads librccl)

@@ -180,6 +180,19 @@ class HipEstepEngine:
     def update_beta(self):
         check(self._L.stm_mstep_update_beta(self._h))
 
+    # -- held-out likelihood ---------------------------------------------------------------
+    def eval_heldout(self, indptr, indices, counts, theta=None):
+        """Per-document held-out per-word log-likelihood against the resident beta (heldout.py:88-97)."""
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        counts = f64(counts)
+        n = len(indptr) - 1
+        th = None if theta is None else f64(theta).reshape(n, self.K)
+        out = np.empty(n, dtype=np.float64)
+        check(self._L.stm_eval_heldout(self._h, n, lptr(indptr), iptr(indices), dptr(counts),
+                                       dptr(th) if th is not None else None, dptr(out)))
+        return out
+
     # -- multi-GPU ---------------------------------------------------------------------
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)

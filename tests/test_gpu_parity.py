@@ -181,6 +181,27 @@ def test_stm_class_reproduces_reference_traces(oracle):
     m.close()
 
 
+def test_eval_heldout_matches_reference(oracle):
+    """Document-completion held-out likelihood (src/modules/heldout.py:88-97, used by src/05_train.py:120)."""
+    from strutopy_amd.corpus import PackedCorpus
+    from strutopy_amd.heldout import eval_heldout
+    g = load_golden("heldout")
+    held = PackedCorpus(g["second_indptr"], g["second_indices"], g["second_counts"], int(g["V"]))
+    assert eval_heldout(held, g["theta"], g["beta"]) == pytest.approx(float(g["mean"]), rel=1e-12)
+    assert eval_heldout(held.to_bow(), g["theta"], g["beta"]) == pytest.approx(float(g["mean"]), rel=1e-12)
+    from strutopy_amd.engine import HipEstepEngine
+    e = HipEstepEngine(0)
+    e.set_corpus(held.indptr, held.indices, held.counts, held.V)
+    e.set_topics(int(g["K"]))
+    e.put_beta(g["beta"])
+    per_doc = e.eval_heldout(held.indptr, held.indices, held.counts, g["theta"])
+    e.close()
+    assert np.allclose(per_doc, g["per_doc"], rtol=1e-12)
+    assert np.allclose(per_doc, oracle.eval_heldout_docs(held.indptr, held.indices, held.counts, g["theta"], g["beta"]), rtol=1e-12)
+    with pytest.raises(ValueError):
+        eval_heldout(held, g["theta"][:5], g["beta"])
+
+
 def test_rccl_all_reduce_path_single_rank():
     """The RCCL binding (dlopen, ncclCommInitRank, ncclAllReduce on the packed device buffer) with a
     one-rank communicator: the reduction is the identity, so every statistic must come back unchanged."""

@@ -83,6 +83,33 @@ def test_encode_covariates_matches_update_mu_preparation():
     assert encode_covariates(None) is None
 
 
+def test_cut_in_half_matches_reference_halves():
+    from strutopy_amd.heldout import cut_in_half
+    g = load_golden("heldout")
+    full = _corpus(load_golden("c1_k10"))
+    first, second = cut_in_half(full)                                   # heldout.py:70-85 on the packed form
+    assert np.array_equal(first.indptr, g["first_indptr"]) and np.array_equal(first.indices, g["first_indices"])
+    assert np.array_equal(second.indptr, g["second_indptr"]) and np.array_equal(second.counts, g["second_counts"])
+    docs = np.array(full.slice(0, 5).to_bow(), dtype=object)
+    a, b = cut_in_half(docs)                                            # and on the reference's list form
+    assert list(a[0]) == list(docs[0][0::2]) and list(b[3]) == list(docs[3][1::2])
+
+
+def test_read_mm_roundtrip(tmp_path):
+    import scipy.io
+    import scipy.sparse
+    from strutopy_amd.corpus import read_mm
+    c = synthetic_corpus(40, 120, 4, n_words=25, seed=9).corpus
+    m = scipy.sparse.csr_matrix((c.counts, c.indices, c.indptr), shape=(c.N, c.V))
+    path = str(tmp_path / "bow.mtx")
+    scipy.io.mmwrite(path, m.astype(np.int64))
+    r = read_mm(path)
+    assert r.N == c.N and r.V == c.V and np.array_equal(r.indptr, c.indptr)
+    for i in range(c.N):   # same (word, count) sets per document
+        sl = slice(c.indptr[i], c.indptr[i + 1])
+        assert dict(zip(r.indices[sl].tolist(), r.counts[sl].tolist())) == dict(zip(c.indices[sl].tolist(), c.counts[sl].tolist()))
+
+
 # ----------------------------------------------------------------------------- STM mirror
 def test_constructor_state_matches_reference_init():
     g = load_golden("toy_ctm")

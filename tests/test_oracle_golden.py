@@ -145,3 +145,11 @@ def test_oracle_thread_count_does_not_change_results(oracle):
     b = oracle.estep(*args, nthreads=0)
     assert np.array_equal(a["eta"], b["eta"]) and np.array_equal(a["bound_doc"], b["bound_doc"])
     assert _rel(a["beta_ss"], b["beta_ss"]) <= 1e-13
+
+
+def test_heldout_restatement_matches_reference(oracle):
+    """eval_heldout of the reference (src/modules/heldout.py:88-97) on the halved C1 corpus."""
+    g = load_golden("heldout")
+    per_doc = oracle.eval_heldout_docs(g["second_indptr"], g["second_indices"], g["second_counts"], g["theta"], g["beta"])
+    assert np.allclose(per_doc, g["per_doc"], rtol=1e-13, atol=0)
+    assert np.mean(per_doc) == pytest.approx(float(g["mean"]), rel=1e-14)

@@ -409,7 +409,29 @@ def case_functions():
          chol=np.asarray(Ls), nu=np.asarray(nus))
 
 
-CASES = dict(toy_ctm=case_toy_ctm, functions=case_functions, edge=case_edge,
+def case_heldout():
+    """Held-out likelihood by document completion (src/modules/heldout.py:70-97, caller src/05_train.py:120):
+    the C1-shaped corpus cut in half, scored with theta / beta of the fitted c1_k10 golden model."""
+    from modules.heldout import cut_in_half, eval_heldout
+    g = np.load(os.path.join(OUT, "c1_k10.npz"))
+    indptr, idx, cnt = g["indptr"], g["indices"], g["counts"]
+    docs = np.zeros(len(indptr) - 1, dtype=np.ndarray)
+    for i in range(len(docs)):
+        sl = slice(indptr[i], indptr[i + 1])
+        docs[i] = list(zip(idx[sl].tolist(), cnt[sl].astype(np.int64).tolist()))
+    first, second = cut_in_half(docs)
+    theta, beta = g["it2_theta"], g["it2_beta_out"]
+    mean = eval_heldout(second, theta, beta)
+    per_doc = np.array([eval_heldout([second[i]], theta[i:i + 1], beta) for i in range(len(second))])
+    i1, x1, c1 = docs_to_csr(list(first))
+    i2, x2, c2 = docs_to_csr(list(second))
+    save("heldout", K=np.int32(g["K"]), V=np.int32(g["V"]), theta=theta, beta=beta,
+         first_indptr=i1, first_indices=x1, first_counts=c1,
+         second_indptr=i2, second_indices=x2, second_counts=c2,
+         mean=np.float64(mean), per_doc=per_doc)
+
+
+CASES = dict(toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
              wiki_k50=case_wiki_k50)
 
