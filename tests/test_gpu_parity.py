@@ -125,6 +125,26 @@ def test_shapes_at_the_limits(oracle, K, nd_max):
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
 
 
+def test_documents_longer_than_the_lds(oracle):
+    """A document whose K x Nd block cannot live in the 160 KB LDS takes the global-slab solver variant;
+    shorter ones in the same corpus stay on chip."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(5)
+    K, V = 40, 6000
+    lens = [5200, 3, 150, 4100, 64, 65, 129, 128, 2000, 90]
+    docs = [np.sort(rng.choice(V, L, replace=False)) for L in lens]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 4, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    n = K - 1
+    N = len(lens)
+    mu = rng.normal(0, 0.2, size=(N, n)); eta = rng.normal(0, 0.2, size=(N, n))
+    siginv, sigent = oracle.preamble(np.eye(n) * 3.0)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    _check(estep_host(*args), oracle.estep(*args, nthreads=0), "long documents")
+
+
 def test_invalid_inputs_raise_like_the_reference():
     from strutopy_amd.engine import HipEstepEngine, estep_host
     g = load_golden("toy_ctm")
