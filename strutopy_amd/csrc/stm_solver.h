@@ -561,8 +561,10 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             for (int r = 0; r < VPL; ++r) {
                 const int i = lane + WAVE * r;
                 double t = 0.0;
-                if (i < n)
+                if (i < n) {   // the sum stays in order (H g must round like scipy's dot up to reassociation-free parts)
+#pragma unroll 4
                     for (int j = 0; j < n; ++j) t += Hs[(size_t)j * n + i] * sv[j];
+                }
                 out[r] = t;
             }
             STM_WAVE_SYNC();
@@ -897,7 +899,8 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     const int j = lane + WAVE * r;
                     if (j < n) {
                         const double sj = s[r], wj = w[r];
-                        for (int i = 0; i < n; ++i) {
+#pragma unroll 4
+                        for (int i = 0; i < n; ++i) {   // rows are independent: several loads in flight
                             const double h = H_ident ? (i == j ? 1.0 : 0.0) : Hs[(size_t)i * n + j];
                             const double si = sv[i], wi = sw[i];
                             Hs[(size_t)i * n + j] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
