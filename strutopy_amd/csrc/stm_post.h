@@ -292,32 +292,62 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         // from the upper triangle of M, which Cholesky never writes.
         double diagA = isn ? M[(size_t)lane * MLD + lane] : 1.0;
         double Ldiag = 1.0;
-        auto cholesky = [&]() -> bool {  // np.linalg.cholesky; L strictly-lower into M, diag in Ldiag
+        // np.linalg.cholesky; L strictly-lower into M, diagonal in Ldiag.  TWO columns per step: the dot
+        // products of columns j and j+1 against the finished columns share the loads of the lane's own row
+        // (3 LDS reads per 2 FMAs), column j+1's last term uses L[:, j] straight from registers
+        // (L[j+1][j] by v_readlane), and the serial per-column tail (pivot broadcast, sqrt, reciprocal,
+        // LDS hand-off) is paid once per pair.
+        auto cholesky = [&]() -> bool {
             bool ok = true;
-            for (int j = 0; j < n; ++j) {
-                double t = 0.0;
+            int j = 0;
+            for (; j + 1 < n; j += 2) {
+                double tA = 0.0, tB = 0.0;
                 if (isn && lane >= j) {
-                    t = (lane == j) ? diagA : M[(size_t)j * MLD + lane];
-                    const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD;
-                    // four independent partial sums: the LDS reads of several l are in flight together
-                    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+                    const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD, *rk = rj + MLD;
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
                     int l = 0;
-                    for (; l + 3 < j; l += 4) {
-                        t0 = fma(ri[l], rj[l], t0);
-                        t1 = fma(ri[l + 1], rj[l + 1], t1);
-                        t2 = fma(ri[l + 2], rj[l + 2], t2);
-                        t3 = fma(ri[l + 3], rj[l + 3], t3);
+                    for (; l + 1 < j; l += 2) {
+                        const double x0 = ri[l], x1 = ri[l + 1];
+                        a0 = fma(x0, rj[l], a0);
+                        b0 = fma(x0, rk[l], b0);
+                        a1 = fma(x1, rj[l + 1], a1);
+                        b1 = fma(x1, rk[l + 1], b1);
                     }
-                    for (; l < j; ++l) t0 = fma(ri[l], rj[l], t0);
-                    t -= (t0 + t1) + (t2 + t3);
+                    if (l < j) {
+                        const double x0 = ri[l];
+                        a0 = fma(x0, rj[l], a0);
+                        b0 = fma(x0, rk[l], b0);
+                    }
+                    tA = ((lane == j) ? diagA : rj[lane]) - (a0 + a1);               // A[lane][j] - ...
+                    if (lane > j) tB = ((lane == j + 1) ? diagA : rk[lane]) - (b0 + b1);
+                }
+                const double dA = lane_bcast(tA, j);
+                if (!(dA > 0.0)) { ok = false; break; }
+                const double ljj = sqrt(dA);
+                const double rjj = 1.0 / ljj;   // LAPACK dpotf2 scales the column by the reciprocal as well
+                const double lA = (isn && lane > j) ? tA * rjj : 0.0;             // L[lane][j]
+                tB -= lA * lane_bcast(lA, j + 1);                                 // ... - L[lane][j] L[j+1][j]
+                const double dB = lane_bcast(tB, j + 1);
+                if (lane == j) Ldiag = ljj;
+                if (isn && lane > j) M[(size_t)lane * MLD + j] = lA;
+                if (!(dB > 0.0)) { ok = false; break; }
+                const double lkk = sqrt(dB);
+                const double rkk = 1.0 / lkk;
+                if (lane == j + 1) Ldiag = lkk;
+                if (isn && lane > j + 1) M[(size_t)lane * MLD + j + 1] = tB * rkk;
+                STM_POST_SYNC();
+            }
+            if (ok && j < n) {   // odd n: the last column on its own
+                double t = 0.0;
+                if (lane == j) {
+                    const double *ri = M + (size_t)lane * MLD;
+                    double a0 = 0.0;
+                    for (int l = 0; l < j; ++l) a0 = fma(ri[l], ri[l], a0);
+                    t = diagA - a0;
                 }
                 const double d = lane_bcast(t, j);
-                if (!(d > 0.0)) { ok = false; break; }
-                const double ljj = sqrt(d);
-                const double rjj = 1.0 / ljj;   // LAPACK dpotf2 scales the column by the reciprocal as well
-                if (lane == j) Ldiag = ljj;
-                if (isn && lane > j) M[(size_t)lane * MLD + j] = t * rjj;
-                STM_POST_SYNC();
+                if (!(d > 0.0)) ok = false;
+                else if (lane == j) Ldiag = sqrt(d);
             }
             STM_POST_SYNC();
             return ok;
@@ -409,29 +439,58 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         const double Rdiag = 1.0 / Ldiag;
         srd[lane] = isn ? Rdiag : 0.0;
         if (!upper) {
-            // R = U^{-1}, U = L^T: column c in lane c, rows from the bottom up; R overwrites the upper triangle
-            for (int i = n - 2; i >= 0; --i) {
-                double t = 0.0;
-                if (isn && lane > i) {
-                    // sum_{l=i+1..lane} L[l][i] R[l][lane]: rows below `lane` contribute nothing (R is upper
-                    // triangular) -- loaded unconditionally and masked, so the reads of several l overlap
-                    const double *ci = M + i, *cl = M + lane;
-                    double t0 = M[(size_t)lane * MLD + i] * Rdiag, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // l == lane term
+            // R = U^{-1}, U = L^T: column c in lane c, rows from the bottom up, TWO rows (i, i-1) per step: both
+            // sums run over the same rows l of R (one load of R[l][lane] feeds two FMAs), row i-1's extra term
+            // takes R[i][lane] from the register it was just computed in.  R overwrites the upper triangle.
+            int i = n - 2;
+            for (; i >= 1; i -= 2) {
+                double tI = 0.0, tH = 0.0;   // rows i and i - 1
+                if (isn && lane >= i) {
+                    const double *ci = M + i, *ch = M + i - 1, *cl = M + lane;
+                    // l == lane terms: L[lane][i] R[lane][lane], L[lane][i-1] R[lane][lane]
+                    double i0 = (lane > i) ? M[(size_t)lane * MLD + i] * Rdiag : 0.0, i1 = 0.0;
+                    double h0 = M[(size_t)lane * MLD + i - 1] * Rdiag, h1 = 0.0;
                     int l = i + 1;
-                    for (; l + 3 < n - 1; l += 4) {
-                        const double r0 = cl[(size_t)l * MLD], r1 = cl[(size_t)(l + 1) * MLD];
-                        const double r2 = cl[(size_t)(l + 2) * MLD], r3 = cl[(size_t)(l + 3) * MLD];
-                        t0 = fma(ci[(size_t)l * MLD], (l < lane) ? r0 : 0.0, t0);
-                        t1 = fma(ci[(size_t)(l + 1) * MLD], (l + 1 < lane) ? r1 : 0.0, t1);
-                        t2 = fma(ci[(size_t)(l + 2) * MLD], (l + 2 < lane) ? r2 : 0.0, t2);
-                        t3 = fma(ci[(size_t)(l + 3) * MLD], (l + 3 < lane) ? r3 : 0.0, t3);
+                    for (; l + 1 < n - 1; l += 2) {
+                        const double r0 = (l < lane) ? cl[(size_t)l * MLD] : 0.0;
+                        const double r1 = (l + 1 < lane) ? cl[(size_t)(l + 1) * MLD] : 0.0;
+                        i0 = fma(ci[(size_t)l * MLD], r0, i0);
+                        h0 = fma(ch[(size_t)l * MLD], r0, h0);
+                        i1 = fma(ci[(size_t)(l + 1) * MLD], r1, i1);
+                        h1 = fma(ch[(size_t)(l + 1) * MLD], r1, h1);
                     }
-                    for (; l < n - 1; ++l) t0 = fma(ci[(size_t)l * MLD], (l < lane) ? cl[(size_t)l * MLD] : 0.0, t0);
-                    t = -((t0 + t1) + (t2 + t3));
+                    if (l < n - 1) {
+                        const double r0 = (l < lane) ? cl[(size_t)l * MLD] : 0.0;
+                        i0 = fma(ci[(size_t)l * MLD], r0, i0);
+                        h0 = fma(ch[(size_t)l * MLD], r0, h0);
+                    }
+                    tI = i0 + i1;
+                    tH = h0 + h1;
                 }
-                const double rii = lane_bcast(Rdiag, i);   // 1 / L[i][i]
-                // row i of R is not read during step i: no barrier needed before the store
-                if (isn && lane > i) M[(size_t)i * MLD + lane] = t * rii;
+                const double rii = lane_bcast(Rdiag, i), rhh = lane_bcast(Rdiag, i - 1);
+                const double lih = uni(M[(size_t)i * MLD + i - 1]);                 // L[i][i-1]
+                const double Ri = (isn && lane > i) ? -tI * rii : 0.0;              // R[i][lane]
+                // row i-1: the l == i term L[i][i-1] R[i][lane] for lane > i (lane == i carried it as its l == lane term)
+                const double tH2 = (lane > i) ? tH + lih * Ri : tH;
+                if (isn && lane > i) M[(size_t)i * MLD + lane] = Ri;
+                if (isn && lane > i - 1) M[(size_t)(i - 1) * MLD + lane] = -tH2 * rhh;
+                STM_POST_SYNC();
+            }
+            if (i == 0) {   // a single row left
+                double t = 0.0;
+                if (isn && lane > 0) {
+                    const double *cl = M + lane;
+                    double t0 = M[(size_t)lane * MLD] * Rdiag, t1 = 0.0;
+                    int l = 1;
+                    for (; l + 1 < n - 1; l += 2) {
+                        t0 = fma(M[(size_t)l * MLD], (l < lane) ? cl[(size_t)l * MLD] : 0.0, t0);
+                        t1 = fma(M[(size_t)(l + 1) * MLD], (l + 1 < lane) ? cl[(size_t)(l + 1) * MLD] : 0.0, t1);
+                    }
+                    if (l < n - 1) t0 = fma(M[(size_t)l * MLD], (l < lane) ? cl[(size_t)l * MLD] : 0.0, t0);
+                    t = -(t0 + t1);
+                }
+                const double r00 = lane_bcast(Rdiag, 0);
+                if (isn && lane > 0) M[lane] = t * r00;
                 STM_POST_SYNC();
             }
         }
