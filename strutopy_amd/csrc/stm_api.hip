@@ -75,6 +75,12 @@ __global__ void transpose_kernel(const double *in, double *out, int R, int C) {
         if (orow + dy < C && oc < R) out[base + (size_t)(orow + dy) * R + oc] = tile[threadIdx.x][threadIdx.y + dy];
 }
 
+// small device -> pinned-host copy done by the GPU itself (no DMA engine round trip)
+__global__ void copy_out_kernel(const double *src, double *dst, size_t cnt) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < cnt) dst[q] = src[q];
+}
+
 }  // namespace
 
 struct stm_handle {
@@ -127,6 +133,10 @@ struct stm_handle {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms[3] = {0, 0, 0};
     bool beta_set = false;
+    // pinned staging for the small per-iteration transfers (siginv in; moments, covariance, sigma_ss out):
+    // a copy to / from fresh pageable memory makes the runtime pin the caller's pages on the fly (ms)
+    void *stage = nullptr;
+    static constexpr size_t STAGE_BYTES = 1 << 20;
 };
 
 static int use_device(stm_handle *h) {
@@ -251,6 +261,7 @@ int stm_create(stm_handle **out, int device_ordinal) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipStreamCreate failed"); }
     for (auto &ev : h->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipEventCreate failed"); }
+    if (hipHostMalloc(&h->stage, stm_handle::STAGE_BYTES, hipHostMallocDefault) != hipSuccess) h->stage = nullptr;
     *out = h;
     return STM_OK;
 }
@@ -267,6 +278,7 @@ void stm_destroy(stm_handle *h) {
     dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu); dfree(h->d_prof);
     dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack);
+    if (h->stage) (void)hipHostFree(h->stage);
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -434,13 +446,28 @@ int stm_get_beta_ss(stm_handle *h, double *beta_ss) {
 
 static int put_vec(stm_handle *h, double *dst, const double *src, size_t cnt) {
     if (!src) return fail(STM_ERR_INVALID, "source pointer is NULL");
-    if (cnt) HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    const size_t bytes = sizeof(double) * cnt;
+    if (cnt && h->stage && bytes <= stm_handle::STAGE_BYTES) {
+        memcpy(h->stage, src, bytes);
+        HIP_TRY(hipMemcpyAsync(dst, h->stage, bytes, hipMemcpyHostToDevice, h->stream));
+    } else if (cnt) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return STM_OK;
 }
 static int get_vec(stm_handle *h, double *dst, const double *src, size_t cnt) {
     if (!dst) return fail(STM_ERR_INVALID, "destination pointer is NULL");
-    if (cnt) HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    const size_t bytes = sizeof(double) * cnt;
+    if (cnt && h->stage && bytes <= stm_handle::STAGE_BYTES) {
+        // the GPU writes into the (device-mapped) pinned staging buffer itself
+        hipLaunchKernelGGL(copy_out_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, src, (double *)h->stage, cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(dst, h->stage, bytes);
+        return STM_OK;
+    }
+    if (cnt) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return STM_OK;
 }
@@ -490,7 +517,13 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
         sig_bound = std::max(sig_bound, r);
     }
     const size_t KV = (size_t)h->A * K * h->V;
-    HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+    if (h->stage && sizeof(double) * (size_t)n * n <= stm_handle::STAGE_BYTES / 2) {   // second half of the staging buffer
+        double *st = (double *)((char *)h->stage + stm_handle::STAGE_BYTES / 2);
+        memcpy(st, siginv, sizeof(double) * (size_t)n * n);
+        HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)h->nrep * n * n, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
