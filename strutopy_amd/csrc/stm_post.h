@@ -278,11 +278,20 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         if (isn) {
             double *mi = M + (size_t)lane * MLD;
             const double thi = sth[lane];
-            for (int j = 0; j < n; ++j) {
-                double h = mi[j] - Ndoc * (thi * sth[j]);
-                if (j == lane) h = h - rowc + Ndoc * thi;
-                const double sij = (P.siginv_diag && j != lane) ? 0.0 : S[(size_t)lane * n + j];
-                mi[j] = h + sij;
+            if (P.siginv_diag) {   // what stm.py:501 produces: only the diagonal of siginv is non-zero
+                const double sii = S[(size_t)lane * n + lane];
+#pragma unroll 4
+                for (int j = 0; j < n; ++j) {
+                    double h = mi[j] - Ndoc * (thi * sth[j]);
+                    if (j == lane) h = h - rowc + Ndoc * thi;
+                    mi[j] = h + ((j == lane) ? sii : 0.0);
+                }
+            } else {
+                for (int j = 0; j < n; ++j) {
+                    double h = mi[j] - Ndoc * (thi * sth[j]);
+                    if (j == lane) h = h - rowc + Ndoc * thi;
+                    mi[j] = h + S[(size_t)lane * n + j];
+                }
             }
         }
         STM_POST_SYNC();

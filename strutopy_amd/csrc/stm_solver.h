@@ -899,11 +899,17 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     const int j = lane + WAVE * r;
                     if (j < n) {
                         const double sj = s[r], wj = w[r];
-#pragma unroll 4
-                        for (int i = 0; i < n; ++i) {   // rows are independent: several loads in flight
-                            const double h = H_ident ? (i == j ? 1.0 : 0.0) : Hs[(size_t)i * n + j];
-                            const double si = sv[i], wi = sw[i];
-                            Hs[(size_t)i * n + j] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
+                        // rows are independent, but the compiler cannot prove that row i+1's load does not alias
+                        // row i's store: fetch the next row before storing the current one
+                        double *hp = Hs + j;
+                        double h = H_ident ? (j == 0 ? 1.0 : 0.0) : hp[0];
+                        double si = sv[0], wi = sw[0];
+                        for (int i = 0; i < n; ++i) {
+                            const int i1 = i + 1 < n ? i + 1 : i;
+                            const double hn = H_ident ? (i1 == j ? 1.0 : 0.0) : hp[(size_t)i1 * n];
+                            const double sin_ = sv[i1], win_ = sw[i1];
+                            hp[(size_t)i * n] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
+                            h = hn; si = sin_; wi = win_;
                         }
                     }
                 }
