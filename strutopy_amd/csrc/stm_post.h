@@ -315,6 +315,15 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD, *rk = rj + MLD;
                     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
                     int l = 0;
+                    for (; l + 3 < j; l += 4) {   // twelve LDS reads in flight per round
+                        const double x0 = ri[l], x1 = ri[l + 1], x2 = ri[l + 2], x3 = ri[l + 3];
+                        const double p0 = rj[l], p1 = rj[l + 1], p2 = rj[l + 2], p3 = rj[l + 3];
+                        const double q0 = rk[l], q1 = rk[l + 1], q2 = rk[l + 2], q3 = rk[l + 3];
+                        a0 = fma(x0, p0, a0); b0 = fma(x0, q0, b0);
+                        a1 = fma(x1, p1, a1); b1 = fma(x1, q1, b1);
+                        a0 = fma(x2, p2, a0); b0 = fma(x2, q2, b0);
+                        a1 = fma(x3, p3, a1); b1 = fma(x3, q3, b1);
+                    }
                     for (; l + 1 < j; l += 2) {
                         const double x0 = ri[l], x1 = ri[l + 1];
                         a0 = fma(x0, rj[l], a0);
@@ -460,6 +469,20 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     double i0 = (lane > i) ? M[(size_t)lane * MLD + i] * Rdiag : 0.0, i1 = 0.0;
                     double h0 = M[(size_t)lane * MLD + i - 1] * Rdiag, h1 = 0.0;
                     int l = i + 1;
+                    for (; l + 3 < n - 1; l += 4) {   // twelve LDS reads in flight per round
+                        const double v0 = cl[(size_t)l * MLD], v1 = cl[(size_t)(l + 1) * MLD];
+                        const double v2 = cl[(size_t)(l + 2) * MLD], v3 = cl[(size_t)(l + 3) * MLD];
+                        const double p0 = ci[(size_t)l * MLD], p1 = ci[(size_t)(l + 1) * MLD];
+                        const double p2 = ci[(size_t)(l + 2) * MLD], p3 = ci[(size_t)(l + 3) * MLD];
+                        const double q0 = ch[(size_t)l * MLD], q1 = ch[(size_t)(l + 1) * MLD];
+                        const double q2 = ch[(size_t)(l + 2) * MLD], q3 = ch[(size_t)(l + 3) * MLD];
+                        const double r0 = (l < lane) ? v0 : 0.0, r1 = (l + 1 < lane) ? v1 : 0.0;
+                        const double r2 = (l + 2 < lane) ? v2 : 0.0, r3 = (l + 3 < lane) ? v3 : 0.0;
+                        i0 = fma(p0, r0, i0); h0 = fma(q0, r0, h0);
+                        i1 = fma(p1, r1, i1); h1 = fma(q1, r1, h1);
+                        i0 = fma(p2, r2, i0); h0 = fma(q2, r2, h0);
+                        i1 = fma(p3, r3, i1); h1 = fma(q3, r3, h1);
+                    }
                     for (; l + 1 < n - 1; l += 2) {
                         const double r0 = (l < lane) ? cl[(size_t)l * MLD] : 0.0;
                         const double r1 = (l + 1 < lane) ? cl[(size_t)(l + 1) * MLD] : 0.0;
