@@ -192,11 +192,11 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
 
 // NW = 1: one wavefront per document.
 // NW = 2: two wavefronts per document (VPL = 1, KREG > 0).  Wave 0 runs the solver state machine
-// and evaluates words 0..63 (registers) + the slab; wave 1 is an evaluation server that holds words
-// 64..127 in ITS registers and computes, per request, its share of the data term, the prior's
-// quadratic form and the gradient df -- the independent pieces of one objective evaluation run on
-// two SIMD slots at once, and the LDS slab shrinks to the words beyond 128 (two barriers per
-// evaluation; everything the solver's control flow sees still passes through wave 0).
+// and evaluates words 0..63 (registers); wave 1 is an evaluation server that holds words 64..127 in ITS
+// registers and the words beyond 128 in the (small) LDS slab and computes, per request, the gradient df
+// and the prior's quadratic form (while wave 0 takes max / exp) and then its share of the data term --
+// the independent pieces of one objective evaluation run on two SIMD slots at once (three barriers
+// per evaluation; everything the solver's control flow sees still passes through wave 0).
 template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1>
 __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
     constexpr int KMAX = 64 * VPL;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
         const int Nd = (int)(P.indptr[doc + 1] - p0);
-        const int NdL = (Nd > VREG && wv == 0) ? Nd - VREG : 0;  // words in the slab (<= ld), wave 0's
+        const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
         const int asp = P.aspect ? P.aspect[doc] : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
 
@@ -499,20 +499,23 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             if (wv == 1) {
                 if (lane < n) g0[0] += xch_gv[lane];
                 for (;;) {
-                    __syncthreads();  // request posted: xch_cmd[0], trial point, exp(eta~ - m) in se[]
+                    __syncthreads();  // (0) request posted: xch_cmd[0] and the trial point
                     const int cmd = uni(xch_cmd[0]);
                     if (cmd & 4) break;
                     xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
-                    if (cmd & 1) {
-                        const double part = wave_sum(data_F(uni(xch_res[2]), se[lane], 0));  // wave 1 owns no slab words
-                        const double q = quad_F();
-                        if (lane == 0) { xch_res[0] = part; xch_res[1] = q; }
-                    }
+                    // while wave 0 works on max / exp(eta~ - m): the pieces that do not need them
+                    double q = 0.0;
+                    if (cmd & 1) q = quad_F();
                     if (cmd & 2) {
                         eval_DF();
                         if (lane < n) xch_gv[lane] = gv[0];
                     }
-                    __syncthreads();  // results posted
+                    __syncthreads();  // (1) exp(eta~ - m) in se[], m in xch_res[2]
+                    if (cmd & 1) {
+                        const double part = wave_sum(data_F(uni(xch_res[2]), se[lane], NdL));  // words 64..127 + the slab
+                        if (lane == 0) { xch_res[0] = part; xch_res[1] = q; }
+                    }
+                    __syncthreads();  // (2) results posted
                 }
                 return;
             }
@@ -521,16 +524,20 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         auto eval_split = [&](bool do_f, bool do_g, double &f_out) __attribute__((always_inline)) {
             double m = 0.0, ssum = 0.0, e_lane = 0.0;
             int icnt = 1;
-            if (do_f) head_F(m, icnt, ssum, e_lane);
             if (lane < n) xch_xt[lane] = xt[0];
-            if (lane == 0) { xch_cmd[0] = (do_f ? 1 : 0) | (do_g ? 2 : 0); xch_res[2] = m; }
-            __syncthreads();
+            if (lane == 0) xch_cmd[0] = (do_f ? 1 : 0) | (do_g ? 2 : 0);
+            __syncthreads();   // (0) wave 1 starts on df and the quadratic form ...
+            if (do_f) {        // ... while this wave takes max / exp(eta~ - m)
+                head_F(m, icnt, ssum, e_lane);
+                if (lane == 0) xch_res[2] = m;
+            }
+            __syncthreads();   // (1)
             double lse = 0.0, part = 0.0;
             if (do_f) {
                 lse = lse_F(m, icnt, ssum);
-                part = wave_sum(data_F(m, e_lane, NdL));
+                part = wave_sum(data_F(m, e_lane, 0));   // words 0..63 (wave 1 owns the slab)
             }
-            __syncthreads();
+            __syncthreads();   // (2)
             if (do_f) {
                 const double part_all = part + uni(xch_res[0]);
                 const double q = uni(xch_res[1]);
