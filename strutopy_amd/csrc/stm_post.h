@@ -72,10 +72,11 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define STM_POST_WPE 2   // waves per SIMD the post kernel is register-budgeted for
 #endif
 
-// doubles of dynamic LDS: max(T, M) + small vectors
+// doubles of dynamic LDS: region 0 = max(T + per-word pack, M), then two 64-entry vectors whose
+// contents change with the phase (20.2 KB at K = 50: eight workgroups per CU)
 inline size_t post_lds_doubles(int n, int MLD) {
-    const size_t t = (size_t)PT * TLD, m = (size_t)n * MLD;
-    return (t > m ? t : m) + 5 * PT + 4 * TW;
+    const size_t t = (size_t)PT * TLD + 4 * TW, m = (size_t)n * MLD;
+    return (t > m ? t : m) + 2 * PT;
 }
 
 template <int NB, bool DUMP>
@@ -86,13 +87,12 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     const int K = P.K, n = P.n, MLD = P.MLD;
     double *T = post_lds;  // [PT][TLD]
     double *M = post_lds;  // [n][MLD] (after the word loop)
-    double *vec = post_lds + ((size_t)PT * TLD > (size_t)n * MLD ? (size_t)PT * TLD : (size_t)n * MLD);
-    double *sex = vec;            // exp(eta~)            (unshifted, stm.py:1000,1088,1114)
-    double *sth = vec + PT;       // stable_softmax(eta~) (stm.py:998,1083)
-    double *sdv = vec + 2 * PT;   // eta - mu broadcast (dense siginv only)
-    double *srow = vec + 3 * PT;  // rowsum(c') per topic
-    double *srd = vec + 4 * PT;   // 1 / diag(L)
-    double *wpar = vec + 5 * PT;  // per word of the tile: { sqrt(c), colsum S, 1 / S, sqrt(c) / S }
+    double *wpar = post_lds + (size_t)PT * TLD;  // word-tile phase only, behind T: per word { sqrt(c), S, 1/S, sqrt(c)/S }
+    double *vec = post_lds + ((size_t)PT * TLD + 4 * TW > (size_t)n * MLD ? (size_t)PT * TLD + 4 * TW : (size_t)n * MLD);
+    double *sex = vec;            // word tiles: exp(eta~) (unshifted, stm.py:1000,1088,1114) ...
+    double *srd = vec;            // ... after the factorisation: 1 / diag(L)
+    double *sth = vec + PT;       // word tiles + assembly: stable_softmax(eta~) (stm.py:998,1083) ...
+    double *sdv = vec + PT;       // ... bound: eta - mu broadcast (dense siginv only)
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
     const bool isn = lane < n, isk = lane < K;
@@ -258,7 +258,6 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         // ---- assemble H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv:
         // the MFMA tiles go to LDS raw, then lane i finishes row i (keeps the 4*NT tile elements
         // from being in flight at once)
-        srow[lane] = rowc;
         {
             int t = 0;
 #pragma unroll
