@@ -14,6 +14,7 @@
 #include "../../include/stm_estep.h"
 #include "stm_mstep.h"
 #include "stm_post.h"
+#include "stm_post_big.h"
 #include "stm_solver.h"
 
 namespace {
@@ -115,6 +116,7 @@ struct stm_handle {
     int kreg = 0;                // register-resident topic count of the solver instantiation (0: none)
     int nw = 1;                  // wavefronts per document in the solver
     int KP = 0;                  // slab row length (doubles)
+    int vpl = 1;                 // vector components per lane in the solver (2 for 64 < K <= 128)
     // optional dumps
     double *d_phi = nullptr;
     int64_t phi_doc = -1;
@@ -149,7 +151,8 @@ using SolverFn = void (*)(stm::SolverParams);
 
 // solver instantiations: KREG topics of the register-resident words (0: none), LDS or global slab,
 // one or two wavefronts per document
-static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1) {
+static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1) {
+    if (vpl == 2) return global_slab ? stm::solver_kernel<2, 0, true> : stm::solver_kernel<2, 0, false>;   // 64 < K <= 128
     if (global_slab) return stm::solver_kernel<1, 0, true>;
     if (nw == 2) {
         switch (kreg) {
@@ -184,6 +187,8 @@ static int plan_solver(stm_handle *h) {
     h->nw = 1;
     if (mode == 0 || mode == 3) h->kreg = K <= 16 ? 16 : K <= 32 ? 32 : K <= 50 ? 50 : 64;
     if (mode == 0) h->nw = 2;
+    h->vpl = K > 64 ? 2 : 1;
+    if (h->vpl == 2) { h->kreg = 0; h->nw = 1; }   // two vector components per lane: beta_d in LDS / HBM only
     const int vreg = h->kreg > 0 ? 64 * h->nw : 0;
     const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
     const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
@@ -219,7 +224,7 @@ static int plan_solver(stm_handle *h) {
         i = j;
     }
     if (max_dyn > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw),
+        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw, h->vpl),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn);
         if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
@@ -349,7 +354,7 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
 int stm_set_topics(stm_handle *h, int32_t K) {
     if (!h || h->V == 0) return fail(STM_ERR_INVALID, "stm_set_topics: set the corpus first");
     if (K < 2) return fail(STM_ERR_INVALID, "stm_set_topics: K must be >= 2");
-    if (K > 64) return fail(STM_ERR_INVALID, "stm_set_topics: K > 64 is not supported by this build yet");
+    if (K > 128) return fail(STM_ERR_INVALID, "stm_set_topics: K > 128 is not supported by this build");
     if (int rc = use_device(h)) return rc;
     h->K = K; h->n = K - 1;
     const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
@@ -560,7 +565,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
-            const SolverFn fn = gr.global ? solver_fn(0, true) : solver_fn(h->kreg, false, h->nw);
+            const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl);
             const unsigned bdim = gr.global ? 64u : 64u * (unsigned)h->nw;
             sp.ld = gr.ld;
             int64_t step = h->chunk;
@@ -584,14 +589,16 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
                                 : (nb <= 1 ? stm::post_kernel<1, false> : nb == 2 ? stm::post_kernel<2, false>
                                    : nb == 3 ? stm::post_kernel<3, false> : stm::post_kernel<4, false>);
         pp.MLD = n | 1;
-        const size_t lds = stm::post_lds_doubles(n, pp.MLD) * sizeof(double);
-        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const bool big = K > stm::PT;   // two topics per lane, VALU only (stm_post_big.h)
+        const PostFn pfn = big ? stm::post_big_kernel : pf;
+        const size_t lds = (big ? stm::post_big_lds_doubles(n, pp.MLD) : stm::post_lds_doubles(n, pp.MLD)) * sizeof(double);
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pf, 64, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, 64, lds));
         per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 8)));
         const int64_t grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
         pp.first = 0; pp.count = h->N;
-        hipLaunchKernelGGL(pf, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
+        hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));

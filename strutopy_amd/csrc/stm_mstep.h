@@ -57,13 +57,15 @@ __global__ void set_mu_kernel(const double *X, const double *gamma, const double
     mu[q] = t;
 }
 
-// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j]; n <= 64.
-// 256 threads: thread (ty, tx) = (t / 64, t % 64) owns column j = tx of rows i = ty, ty+4, ...
+// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j]; n <= 128.
+// 256 threads: thread (ty, tx) = (t / 64, t % 64) owns column j = tx + 64 blockIdx.y of rows
+// i = 64 blockIdx.z + ty, ty+4, ...  (grid y = z = ceil(n / 64))
 __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, const double *mu, int64_t N,
                                                          int n, double *part) {
     constexpr int TD = 32;  // documents per LDS tile
-    __shared__ double diff[TD][65];
+    __shared__ double diff[TD][129];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int jc = tx + 64 * blockIdx.y, ib = 64 * blockIdx.z;
     double acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0;
@@ -72,37 +74,38 @@ __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, cons
     const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
     for (int64_t base = d0; base < d1; base += TD) {
         const int cnt = (int)((d1 - base) < TD ? (d1 - base) : TD);
-        for (int q = threadIdx.x; q < TD * 64; q += 256) {
-            const int dd = q >> 6, i = q & 63;
+        for (int q = threadIdx.x; q < TD * 128; q += 256) {
+            const int dd = q >> 7, i = q & 127;
             diff[dd][i] = (dd < cnt && i < n) ? eta[(base + dd) * n + i] - mu[(base + dd) * n + i] : 0.0;
         }
         __syncthreads();
         for (int dd = 0; dd < cnt; ++dd) {
-            const double cj = diff[dd][tx];
+            const double cj = diff[dd][jc];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fma(diff[dd][ty + 4 * r], cj, acc[r]);
+            for (int r = 0; r < 16; ++r) acc[r] = fma(diff[dd][ib + ty + 4 * r], cj, acc[r]);
         }
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int i = ty + 4 * r;
-        if (i < n && tx < n) part[(size_t)blockIdx.x * n * n + (size_t)i * n + tx] = acc[r];
+        const int i = ib + ty + 4 * r;
+        if (i < n && jc < n) part[(size_t)blockIdx.x * n * n + (size_t)i * n + jc] = acc[r];
     }
 }
 
 // column sums of the word-major beta_ss: part[block][k] = sum over the block's words of bssT[v][k]
 __global__ __launch_bounds__(256) void beta_rowsum_kernel(const double *bssT, int V, int K, double *part) {
-    const int k = threadIdx.x & 63, sub = threadIdx.x >> 6;  // 4 word lanes x 64 topics
+    const int kl = threadIdx.x & 63, sub = threadIdx.x >> 6;  // 4 word lanes x 64 topics (x blockIdx.y)
+    const int k = kl + 64 * blockIdx.y;
     __shared__ double sh[4][64];
     const int chunk = (V + gridDim.x - 1) / gridDim.x;
     const int v0 = blockIdx.x * chunk, v1 = v0 + chunk < V ? v0 + chunk : V;
     double t = 0.0;
     if (k < K)
         for (int v = v0 + sub; v < v1; v += 4) t += bssT[(size_t)v * K + k];
-    sh[sub][k] = t;
+    sh[sub][kl] = t;
     __syncthreads();
-    if (sub == 0 && k < K) part[(size_t)blockIdx.x * K + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+    if (sub == 0 && k < K) part[(size_t)blockIdx.x * K + k] = (sh[0][kl] + sh[1][kl]) + (sh[2][kl] + sh[3][kl]);
 }
 // betaT[v][k] = bssT[v][k] / rowsum[k] where rowsum != 0 else 0 (2-D beta, stm.py:741-745)
 __global__ void beta_normalise_kernel(const double *bssT, const double *rowsum, int64_t VK, int K, double *betaT) {

@@ -102,9 +102,10 @@ def test_hessian_cholesky_nu_per_document(monkeypatch):
         assert _rel(phi, g["it0_phi_last"]) <= 1e-7, name
 
 
-@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (64, 90)])
+@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (64, 90), (65, 120), (100, 300), (128, 90)])
 def test_shapes_at_the_limits(oracle, K, nd_max):
-    """smallest / largest K of this build and documents longer than one 64-word tile."""
+    """smallest / largest K of this build (K <= 64: one topic per lane + MFMA post kernel; 64 < K <= 128:
+    two topics per lane) and documents longer than one 64-word tile."""
     from strutopy_amd.engine import estep_host
     rng = np.random.default_rng(K)
     V, N = 900, 70
@@ -123,6 +124,54 @@ def test_shapes_at_the_limits(oracle, K, nd_max):
     dense = np.linalg.inv(sigma)          # a caller-supplied dense siginv takes the general path
     args = (indptr, indices, counts, beta, mu, eta, dense, sigent)
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
+
+
+def test_k100_two_topics_per_lane(oracle, monkeypatch):
+    """BASELINE config 4's K = 100: the two-topics-per-lane solver and post kernel, per-document
+    Hessian / Cholesky / nu against the oracle, and the device M-step at n = 99 (resident EM iterations
+    against the host-NumPy M-step)."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import PackedCorpus
+    from strutopy_amd.engine import HipEstepEngine
+    rng = np.random.default_rng(100)
+    K, V, N = 100, 2500, 48
+    lens = rng.integers(1, 260, size=N)
+    docs = [np.sort(rng.choice(V, int(L), replace=False)) for L in lens]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 5, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    n = K - 1
+    mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
+    siginv, sigent = oracle.preamble(np.eye(n) * 20.0)
+    monkeypatch.setenv("STM_DEBUG_DUMP", "1")
+    e = HipEstepEngine(0)
+    e.set_corpus(indptr, indices, counts, V)
+    e.set_topics(K)
+    e.put_beta(beta); e.put_mu(mu); e.put_eta(eta)
+    e.estep(siginv, sigent)
+    hess, chol, nu = e.debug_mats()
+    phi = e.get_phi_last()
+    e.close()
+    monkeypatch.delenv("STM_DEBUG_DUMP")
+    o = oracle.estep(indptr, indices, counts, beta, mu, eta, siginv, sigent, dump_mats=True, nthreads=0)
+    assert _rel(hess, o["hess"]) <= 1e-9
+    assert _rel(chol, o["chol"]) <= 1e-9
+    assert _rel(nu, o["nu"]) <= 1e-8
+    assert _rel(phi, o["phi_last"]) <= 1e-8
+    c = PackedCorpus(indptr, indices, counts, V)
+    X = rng.integers(0, 2, size=(N, 2)).astype(np.float64)   # 0/1 columns are used as they are (stm.py:656-671)
+    out = []
+    for resident in (True, False):
+        m = STM(documents=c, dictionary=None, content=False, K=K, X=X, kappa_interactions=False, max_em_iter=2,
+                sigma_prior=0, convergence_threshold=1e-12, init_type="random", model_type="STM")
+        m.expectation_maximization(saving=False, resident=resident)
+        out.append((np.array(m.last_bounds), m.beta.copy(), m.sigma.copy(), m.gamma.copy()))
+        m.close()
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-9)
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-6, atol=1e-12)
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-6, atol=1e-9)
+    assert np.allclose(out[0][3], out[1][3], rtol=1e-6, atol=1e-8)
 
 
 def test_documents_longer_than_the_lds(oracle):

@@ -8,7 +8,7 @@ under-reports coalesced reads by a pattern-dependent factor (exactly 2x for 16-B
 be calibrated on a known byte count in the same access pattern.  Calibration kernel: covariance_kernel,
 which streams eta and mu exactly once with 8-B/lane coalesced loads (2 * N * (K-1) * 8 bytes).
 
-usage: traffic_summary.py fetch.csv write.csv out.json [N K]
+usage: traffic_summary.py fetch.csv write.csv out.json [N K V words]
 """
 import collections, csv, json, sys
 
@@ -28,7 +28,9 @@ N = int(sys.argv[4]) if len(sys.argv) > 4 else 100000
 K = int(sys.argv[5]) if len(sys.argv) > 5 else 50
 known = 2.0 * N * (K - 1) * 8
 cal = known / (fetch.get("stm::covariance_kernel", 0.0) * 1024) if fetch.get("stm::covariance_kernel") else None
-out = {"_units": "bytes per E-step (all dispatches of the kernel in one EM iteration)", "_fetch_calibration": cal,
+out = {"_workload": {"docs": N, "vocab": int(sys.argv[6]) if len(sys.argv) > 6 else 10000, "topics": K,
+                     "words": int(sys.argv[7]) if len(sys.argv) > 7 else 150},
+       "_units": "bytes per E-step (all dispatches of the kernel in one EM iteration)", "_fetch_calibration": cal,
        "_note": "FETCH_SIZE*1024*calibration + WRITE_SIZE*1024; calibration = known bytes of covariance_kernel / its FETCH_SIZE"}
 for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, 0.0) * 1024 * (cal or 1.0)
