@@ -582,12 +582,20 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     if ((dbg_stage & 2) && h->N > 0) {
         // persistent single-wave workgroups: as many as the LDS / register budget keeps resident
         using PostFn = void (*)(stm::PostParams);
-        const int nb = (K + 15) / 16;
+        // the matrix is n x n (n = K - 1): 16 x 16 MFMA blocks, and when n is one past a multiple of 16
+        // (K = 50: 49 = 3 * 16 + 1) the last row / column rides on the VALU instead of a padded block
+        const bool rem = n > 16 && n % 16 == 1 && env_int("STM_POST_REM", 1);
+        const int nb = rem ? n / 16 : (n + 15) / 16;
         const bool dumps = pp.nu_out != nullptr;
-        const PostFn pf = dumps ? (nb <= 1 ? stm::post_kernel<1, true> : nb == 2 ? stm::post_kernel<2, true>
-                                   : nb == 3 ? stm::post_kernel<3, true> : stm::post_kernel<4, true>)
-                                : (nb <= 1 ? stm::post_kernel<1, false> : nb == 2 ? stm::post_kernel<2, false>
-                                   : nb == 3 ? stm::post_kernel<3, false> : stm::post_kernel<4, false>);
+        PostFn pf;
+        if (rem)
+            pf = dumps ? (nb == 1 ? stm::post_kernel<1, 1, true> : nb == 2 ? stm::post_kernel<2, 1, true> : stm::post_kernel<3, 1, true>)
+                       : (nb == 1 ? stm::post_kernel<1, 1, false> : nb == 2 ? stm::post_kernel<2, 1, false> : stm::post_kernel<3, 1, false>);
+        else
+            pf = dumps ? (nb <= 1 ? stm::post_kernel<1, 0, true> : nb == 2 ? stm::post_kernel<2, 0, true>
+                          : nb == 3 ? stm::post_kernel<3, 0, true> : stm::post_kernel<4, 0, true>)
+                       : (nb <= 1 ? stm::post_kernel<1, 0, false> : nb == 2 ? stm::post_kernel<2, 0, false>
+                          : nb == 3 ? stm::post_kernel<3, 0, false> : stm::post_kernel<4, 0, false>);
         pp.MLD = n | 1;
         const bool big = K > stm::PT;   // two topics per lane, VALU only (stm_post_big.h)
         const PostFn pfn = big ? stm::post_big_kernel : pf;

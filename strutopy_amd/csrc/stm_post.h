@@ -79,9 +79,13 @@ inline size_t post_lds_doubles(int n, int MLD) {
     return (t > m ? t : m) + 2 * PT;
 }
 
-template <int NB, bool DUMP>
+// NB 16 x 16 blocks cover the (K-1)^2 matrix on the matrix cores; REM == 1: n = 16 NB + 1 exactly (K = 50:
+// 49 = 3 * 16 + 1), and the one row / column beyond the blocks is carried on the VALU (one double per
+// lane) instead of padding to NB + 1 blocks -- 6 accumulator tiles instead of 10, twice (b b^T and nu).
+template <int NB, int REM, bool DUMP>
 __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int R0 = 16 * NB;   // index of the remainder row (REM == 1)
     extern __shared__ __attribute__((aligned(16))) double post_lds[];
     const int lane = threadIdx.x;
     const int K = P.K, n = P.n, MLD = P.MLD;
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     v4d acc_nu[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc_nu[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double nu_rem = 0.0;   // REM: running sum of nu[lane][R0]
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
         const int64_t ticket = P.first + tk;
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         v4d acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        double hrem = 0.0;   // REM: (b b^T)[lane][R0]
         const int kc = (K + 3) >> 2;  // topics per quarter in step 2
 
         // Software pipeline over the tiles: while tile t is reduced / scattered / multiplied, the beta rows
@@ -246,6 +252,18 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                         for (int bj = bi; bj < NB; ++bj, ++t)
                             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
                 }
+                if (REM && isn) {
+                    const double2 *own = reinterpret_cast<const double2 *>(T + (size_t)lane * TLD);
+                    const double2 *rem = reinterpret_cast<const double2 *>(T + (size_t)R0 * TLD);
+                    double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+                    for (int w = 0; w < TW / 2; ++w) {
+                        const double2 a = own[w], b = rem[w];
+                        h0 = fma(a.x, b.x, h0);
+                        h1 = fma(a.y, b.y, h1);
+                    }
+                    hrem += h0 + h1;
+                }
             }
             STM_POST_SYNC();
             my_idx = idx1; my_c = c1; idx1 = idx2; c1 = c2;
@@ -272,6 +290,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                             if (bi != bj) M[(size_t)j * MLD + i] = acc[t][r];
                         }
                     }
+            if (REM && isn) {
+                M[(size_t)lane * MLD + R0] = hrem;
+                M[(size_t)R0 * MLD + lane] = hrem;
+            }
         }
         STM_POST_SYNC();
         if (isn) {
@@ -554,6 +576,16 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 for (int bj = bi; bj < NB; ++bj, ++t)
                     acc_nu[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc_nu[t], 0, 0, 0);
         }
+        if (REM) {   // nu[i][R0] = R[i][R0] R[R0][R0]: R is upper triangular and R0 is its last row
+            double v = 0.0;
+            if (lane == R0) v = Rdiag * Rdiag;
+            else if (isn && !upper) v = M[(size_t)lane * MLD + R0] * srd[R0];
+            nu_rem += v;
+            if (DUMP && P.nu_out && isn) {
+                P.nu_out[(size_t)doc * n * n + (size_t)lane * n + R0] = v;
+                P.nu_out[(size_t)doc * n * n + (size_t)R0 * n + lane] = v;
+            }
+        }
         if (DUMP) {  // parity-test build: per-document nu
             int t = 0;
 #pragma unroll
@@ -594,6 +626,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                         if (bi != bj) unsafeAtomicAdd(sig_acc + (size_t)j * n + i, acc_nu[t][r]);
                     }
                 }
+        if (REM && isn) {
+            unsafeAtomicAdd(sig_acc + (size_t)lane * n + R0, nu_rem);
+            if (lane != R0) unsafeAtomicAdd(sig_acc + (size_t)R0 * n + lane, nu_rem);
+        }
     }
 }
 

@@ -906,17 +906,25 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     const int j = lane + WAVE * r;
                     if (j < n) {
                         const double sj = s[r], wj = w[r];
-                        // rows are independent, but the compiler cannot prove that row i+1's load does not alias
-                        // row i's store: fetch the next row before storing the current one
+                        // rows are independent, but the compiler cannot prove that a later row's load does not
+                        // alias an earlier row's store: fetch four rows, then store four (LDS latency paid once per batch)
                         double *hp = Hs + j;
-                        double h = H_ident ? (j == 0 ? 1.0 : 0.0) : hp[0];
-                        double si = sv[0], wi = sw[0];
-                        for (int i = 0; i < n; ++i) {
-                            const int i1 = i + 1 < n ? i + 1 : i;
-                            const double hn = H_ident ? (i1 == j ? 1.0 : 0.0) : hp[(size_t)i1 * n];
-                            const double sin_ = sv[i1], win_ = sw[i1];
+                        int i = 0;
+                        for (; i + 3 < n; i += 4) {
+                            double h[4], si[4], wi[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                h[q] = H_ident ? (i + q == j ? 1.0 : 0.0) : hp[(size_t)(i + q) * n];
+                                si[q] = sv[i + q]; wi[q] = sw[i + q];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                hp[(size_t)(i + q) * n] = h[q] - rhok * (si[q] * wj + wi[q] * sj) + cc * (si[q] * sj);
+                        }
+                        for (; i < n; ++i) {
+                            const double h = H_ident ? (i == j ? 1.0 : 0.0) : hp[(size_t)i * n];
+                            const double si = sv[i], wi = sw[i];
                             hp[(size_t)i * n] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
-                            h = hn; si = sin_; wi = win_;
                         }
                     }
                 }

@@ -369,3 +369,66 @@ def test_full_size_repeatable_and_shard_linear(full_size):
         es.close()
     assert _rel(acc_b, f["beta_ss"]) <= 1e-12 and _rel(acc_s, f["sigma_ss"]) <= 1e-12
     assert acc_bound == pytest.approx(f["bound"], rel=1e-13)
+
+
+def _c2_corpus(g):
+    """The corpus tools/make_golden_c2.py ran the reference on, regenerated and checked against its checksums."""
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(int(g["n_docs"]), int(g["V_requested"]), int(g["K"]), n_words=int(g["n_words"]), seed=int(g["seed"]))
+    c = syn.corpus
+    assert c.V == int(g["V"]) and int(c.indptr[-1]) == int(g["nnz"])
+    assert int(np.sum(c.indices.astype(np.int64) * (np.arange(len(c.indices)) % 9973))) == int(g["checksum_indices"])
+    assert float(np.sum(c.counts * (np.arange(len(c.counts)) % 9973))) == float(g["checksum_counts"])
+    return syn
+
+
+def test_full_size_against_the_reference_itself():
+    """BASELINE.json configs[1] end to end against the imported reference (tests/golden/c2_full.npz, made by
+    tools/make_golden_c2.py): two EM iterations over all 100k documents -- ELBO trace, every document's scipy
+    status / nit / PD path, sufficient statistics and the M-step results, through both the reference's own
+    call pattern (E_step -> M_step on the host) and the device-resident loop."""
+    from strutopy_amd import STM
+    g = load_golden("c2_full")
+    syn = _c2_corpus(g)
+    K, rows, cols = int(g["K"]), g["sample_docs"], g["sample_cols"]
+
+    def model():
+        return STM(documents=syn.corpus, dictionary=None, content=False, K=K, X=syn.X, kappa_interactions=False,
+                   max_em_iter=2, sigma_prior=0, convergence_threshold=1e-12, init_type="random", model_type="STM")
+
+    m = model()
+    assert np.array_equal(m.beta[:, cols], g["beta0_cols"])
+    for it in range(2):
+        p = f"it{it}_"
+        beta_ss, sigma_ss = m.E_step()
+        d = m.solver_diagnostics()
+        assert m.bound == pytest.approx(float(g[p + "bound"]), rel=1e-10)       # north_star asks 1e-6
+        if it == 0:   # identical inputs: every document takes the reference's path
+            for k in ("status", "nit", "pd_path"):
+                assert np.array_equal(d[k], g[p + k]), k
+        else:         # inputs differ by the rounding of one M-step: allow a handful of documents to flip
+            for k in ("status", "nit", "pd_path"):
+                assert np.mean(d[k] != g[p + k]) <= 1e-4, k
+        assert np.max(np.abs(m.eta[rows] - g[p + "eta_sample"])) <= 1e-7
+        assert np.max(np.abs(m.theta[rows] - g[p + "theta_sample"])) <= 1e-7
+        assert np.allclose(m.eta.sum(axis=0), g[p + "eta_colsum"], rtol=1e-7, atol=1e-6)
+        assert np.allclose(m.theta.sum(axis=0), g[p + "theta_colsum"], rtol=1e-9)
+        assert _rel(sigma_ss, g[p + "sigma_ss"]) <= 1e-8
+        assert _rel(beta_ss.sum(axis=1), g[p + "beta_ss_rowsum"]) <= 1e-9
+        assert _rel(beta_ss.sum(axis=0), g[p + "beta_ss_colsum"]) <= 1e-9
+        assert _rel(beta_ss[:, cols], g[p + "beta_ss_cols"]) <= 1e-7
+        assert np.allclose(m.siginv, g[p + "siginv"], rtol=1e-9, atol=1e-14)
+        m.M_step(beta_ss, sigma_ss)
+        assert np.allclose(m.gamma, g[p + "gamma"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(m.sigma, g[p + "sigma_out"], rtol=1e-7, atol=1e-9)
+        assert np.allclose(m.beta[:, cols], g[p + "beta_out_cols"], rtol=1e-7, atol=1e-14)
+        assert np.allclose(m.mu[rows], g[p + "mu_sample"], rtol=1e-6, atol=1e-9)
+    m.close()
+    m = model()
+    m.expectation_maximization(saving=False)                                   # device-resident E + M
+    assert m.last_bounds[0] == pytest.approx(float(g["it0_bound"]), rel=1e-10)
+    assert m.last_bounds[1] == pytest.approx(float(g["it1_bound"]), rel=1e-9)
+    assert np.allclose(m.sigma, g["it1_sigma_out"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(m.beta[:, cols], g["it1_beta_out_cols"], rtol=1e-6, atol=1e-13)
+    assert np.max(np.abs(m.eta[rows] - g["it1_eta_sample"])) <= 1e-6
+    m.close()

@@ -153,3 +153,25 @@ def test_heldout_restatement_matches_reference(oracle):
     per_doc = oracle.eval_heldout_docs(g["second_indptr"], g["second_indices"], g["second_counts"], g["theta"], g["beta"])
     assert np.allclose(per_doc, g["per_doc"], rtol=1e-13, atol=0)
     assert np.mean(per_doc) == pytest.approx(float(g["mean"]), rel=1e-14)
+
+
+def test_oracle_on_the_full_size_reference_golden(oracle):
+    """tests/golden/c2_full.npz holds the reference's own E-step over BASELINE configs[1] (100k documents,
+    V=10k, K=50; tools/make_golden_c2.py).  The oracle is run on its 500 sampled documents of EM iteration 0."""
+    from strutopy_amd.corpus import synthetic_corpus
+    g = load_golden("c2_full")
+    K, n = int(g["K"]), int(g["K"]) - 1
+    c = synthetic_corpus(int(g["n_docs"]), int(g["V_requested"]), K, n_words=int(g["n_words"]), seed=int(g["seed"])).corpus
+    assert int(np.sum(c.indices.astype(np.int64) * (np.arange(len(c.indices)) % 9973))) == int(g["checksum_indices"])
+    rows = g["sample_docs"]
+    lens = c.indptr[rows + 1] - c.indptr[rows]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    take = np.concatenate([np.arange(c.indptr[r], c.indptr[r + 1]) for r in rows])
+    beta = reference_beta0(K, c.V)
+    z = np.zeros((len(rows), n))
+    o = oracle.estep(indptr, c.indices[take], c.counts[take], beta, z, z, g["it0_siginv"], float(g["it0_sigmaentropy"]), nthreads=0)
+    assert np.array_equal(o["status"], g["it0_status"][rows]) and np.array_equal(o["nit"], g["it0_nit"][rows])
+    assert np.array_equal(o["pd_path"], g["it0_pd_path"][rows])
+    assert np.max(np.abs(o["eta"] - g["it0_eta_sample"])) <= 1e-7
+    assert np.max(np.abs(o["theta"] - g["it0_theta_sample"])) <= 1e-7
+    assert np.max(np.abs(o["bound_doc"] - g["it0_bound_doc_sample"]) / np.abs(g["it0_bound_doc_sample"])) <= 1e-9
