@@ -72,11 +72,21 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define STM_POST_WPE 2   // waves per SIMD the post kernel is register-budgeted for
 #endif
 
-// doubles of dynamic LDS: region 0 = max(T + per-word pack, M), then two 64-entry vectors whose
-// contents change with the phase (20.2 KB at K = 50: eight workgroups per CU)
-inline size_t post_lds_doubles(int n, int MLD) {
+// Leading dimension of the LDS matrix: rows start 16-byte aligned and are read two doubles at a time
+// (ds_read_b128); MLD = 2 * odd makes the 16-lane groups of such a lane-strided read hit distinct bank quads
+// (tools/microbench/lds_read.hip: 1.5x the throughput of ds_read_b64 at an odd stride).
+inline int post_mld(int n) {
+    int m = n + (n & 1);
+    if ((m & 3) != 2) m += 2;
+    return m;
+}
+// entries of the two per-topic LDS vectors: the per-word sums read topics [0, 4 * ceil(K / 4))
+__host__ __device__ inline int post_vec_len(int K) { return 4 * ((K + 3) >> 2); }
+// doubles of dynamic LDS: region 0 = max(T + per-word pack, M), then two per-topic vectors whose contents
+// change with the phase (20.4 KB at K = 50: eight workgroups per CU)
+inline size_t post_lds_doubles(int n, int MLD, int K) {
     const size_t t = (size_t)PT * TLD + 4 * TW, m = (size_t)n * MLD;
-    return (t > m ? t : m) + 2 * PT;
+    return (t > m ? t : m) + 2 * (size_t)post_vec_len(K);
 }
 
 // NB 16 x 16 blocks cover the (K-1)^2 matrix on the matrix cores; REM == 1: n = 16 NB + 1 exactly (K = 50:
@@ -95,8 +105,9 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     double *vec = post_lds + ((size_t)PT * TLD + 4 * TW > (size_t)n * MLD ? (size_t)PT * TLD + 4 * TW : (size_t)n * MLD);
     double *sex = vec;            // word tiles: exp(eta~) (unshifted, stm.py:1000,1088,1114) ...
     double *srd = vec;            // ... after the factorisation: 1 / diag(L)
-    double *sth = vec + PT;       // word tiles + assembly: stable_softmax(eta~) (stm.py:998,1083) ...
-    double *sdv = vec + PT;       // ... bound: eta - mu broadcast (dense siginv only)
+    const int KV = post_vec_len(K);
+    double *sth = vec + KV;       // word tiles + assembly: stable_softmax(eta~) (stm.py:998,1083) ...
+    double *sdv = vec + KV;       // ... bound: eta - mu broadcast (dense siginv only)
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
     const bool isn = lane < n, isk = lane < K;
@@ -130,8 +141,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         const double ssum = wave_sum(es);
         const double ths = es / ssum;
         STM_POST_SYNC();  // the previous document's readers of M / vec are done
-        sex[lane] = ex;
-        sth[lane] = isk ? ths : 0.0;
+        if (lane < KV) {
+            sex[lane] = ex;
+            sth[lane] = isk ? ths : 0.0;
+        }
         // topic rows K..63 of T stay zero for the whole document
         for (int q = lane; q < PT * TLD; q += WAVE) T[q] = 0.0;
         STM_POST_SYNC();
@@ -301,11 +314,21 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
             const double thi = sth[lane];
             if (P.siginv_diag) {   // what stm.py:501 produces: only the diagonal of siginv is non-zero
                 const double sii = S[(size_t)lane * n + lane];
-#pragma unroll 4
-                for (int j = 0; j < n; ++j) {
+                double2 *mi2 = reinterpret_cast<double2 *>(mi);
+                const double2 *th2 = reinterpret_cast<const double2 *>(sth);
+                int j = 0;
+#pragma unroll 2
+                for (; j + 1 < n; j += 2) {
+                    const double2 mv = mi2[j >> 1], tv = th2[j >> 1];
+                    double h0 = mv.x - Ndoc * (thi * tv.x), h1 = mv.y - Ndoc * (thi * tv.y);
+                    if (j == lane) h0 = (h0 - rowc + Ndoc * thi) + sii;
+                    if (j + 1 == lane) h1 = (h1 - rowc + Ndoc * thi) + sii;
+                    mi2[j >> 1] = make_double2(h0, h1);
+                }
+                if (j < n) {
                     double h = mi[j] - Ndoc * (thi * sth[j]);
-                    if (j == lane) h = h - rowc + Ndoc * thi;
-                    mi[j] = h + ((j == lane) ? sii : 0.0);
+                    if (j == lane) h = (h - rowc + Ndoc * thi) + sii;
+                    mi[j] = h;
                 }
             } else {
                 for (int j = 0; j < n; ++j) {
@@ -336,14 +359,14 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD, *rk = rj + MLD;
                     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
                     int l = 0;
-                    for (; l + 3 < j; l += 4) {   // twelve LDS reads in flight per round
-                        const double x0 = ri[l], x1 = ri[l + 1], x2 = ri[l + 2], x3 = ri[l + 3];
-                        const double p0 = rj[l], p1 = rj[l + 1], p2 = rj[l + 2], p3 = rj[l + 3];
-                        const double q0 = rk[l], q1 = rk[l + 1], q2 = rk[l + 2], q3 = rk[l + 3];
-                        a0 = fma(x0, p0, a0); b0 = fma(x0, q0, b0);
-                        a1 = fma(x1, p1, a1); b1 = fma(x1, q1, b1);
-                        a0 = fma(x2, p2, a0); b0 = fma(x2, q2, b0);
-                        a1 = fma(x3, p3, a1); b1 = fma(x3, q3, b1);
+                    for (; l + 3 < j; l += 4) {   // six 16-byte LDS reads in flight per round (rows are 16-byte aligned)
+                        const double2 xa = *reinterpret_cast<const double2 *>(ri + l), xb = *reinterpret_cast<const double2 *>(ri + l + 2);
+                        const double2 pa = *reinterpret_cast<const double2 *>(rj + l), pb = *reinterpret_cast<const double2 *>(rj + l + 2);
+                        const double2 qa = *reinterpret_cast<const double2 *>(rk + l), qb = *reinterpret_cast<const double2 *>(rk + l + 2);
+                        a0 = fma(xa.x, pa.x, a0); b0 = fma(xa.x, qa.x, b0);
+                        a1 = fma(xa.y, pa.y, a1); b1 = fma(xa.y, qa.y, b1);
+                        a0 = fma(xb.x, pb.x, a0); b0 = fma(xb.x, qb.x, b0);
+                        a1 = fma(xb.y, pb.y, a1); b1 = fma(xb.y, qb.y, b1);
                     }
                     for (; l + 1 < j; l += 2) {
                         const double x0 = ri[l], x1 = ri[l + 1];
@@ -476,7 +499,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066)
         const double Rdiag = 1.0 / Ldiag;
-        srd[lane] = isn ? Rdiag : 0.0;
+        if (isn) srd[lane] = Rdiag;
         if (!upper) {
             // R = U^{-1}, U = L^T: column c in lane c, rows from the bottom up, TWO rows (i, i-1) per step: both
             // sums run over the same rows l of R (one load of R[l][lane] feeds two FMAs), row i-1's extra term
