@@ -597,7 +597,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
                        : (nb <= 1 ? stm::post_kernel<1, 0, false> : nb == 2 ? stm::post_kernel<2, 0, false>
                           : nb == 3 ? stm::post_kernel<3, 0, false> : stm::post_kernel<4, 0, false>);
         const bool big = K > stm::PT;   // two topics per lane, VALU only (stm_post_big.h)
-        pp.MLD = big ? (n | 1) : stm::post_mld(n);
+        pp.MLD = big ? ((n + 1) | 1) : stm::post_mld(n);   // big: odd, with at least one padding column
         const PostFn pfn = big ? stm::post_big_kernel : pf;
         const size_t lds = (big ? stm::post_big_lds_doubles(n, pp.MLD) : stm::post_lds_doubles(n, pp.MLD, K)) * sizeof(double);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

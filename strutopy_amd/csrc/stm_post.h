@@ -157,6 +157,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
         double hrem = 0.0;   // REM: (b b^T)[lane][R0]
         const int kc = (K + 3) >> 2;  // topics per quarter in step 2
+        long long tq[4] = {0, 0, 0, 0};
 
         // Software pipeline over the tiles: while tile t is reduced / scattered / multiplied, the beta rows
         // of tile t+1 are already in flight (into the registers the LDS transpose of tile t has just
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         load_rows(0, my_idx);
         for (int t0 = 0; t0 < Nd; t0 += TW) {
             const int nw = Nd - t0 < TW ? Nd - t0 : TW;
+            long long c0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
             // -- 1. the tile's 16 coalesced rows (issued one tile ago), transposed into T[topic][word]
             if (isk) {
                 double2 *row = reinterpret_cast<double2 *>(T + (size_t)lane * TLD);
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
             if (t0 + TW < Nd) load_rows(t0 + TW, idx1);
             load_ids(t0 + 2 * TW, idx2, c2);
             STM_POST_SYNC();
+            if (P.prof) { const long long c1 = __builtin_readcyclecounter(); tq[0] += c1 - c0; c0 = c1; }
             // -- 2. per-word sums, lane = (word fr, topic quarter fq)
             {
                 double Sp = 0.0, Lp = 0.0;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 }
             }
             STM_POST_SYNC();
+            if (P.prof) { const long long c1 = __builtin_readcyclecounter(); tq[1] += c1 - c0; c0 = c1; }
             // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
             if (isk) {
                 double *trow = T + (size_t)lane * TLD;
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 }
             }
             STM_POST_SYNC();
+            if (P.prof) { const long long c1 = __builtin_readcyclecounter(); tq[2] += c1 - c0; c0 = c1; }
             // -- 4. b b^T on the matrix cores, upper block triangle
             if (!(P.debug_flags & 2)) {
 #pragma unroll
@@ -279,8 +284,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 }
             }
             STM_POST_SYNC();
+            if (P.prof) { const long long c1t = __builtin_readcyclecounter(); tq[3] += c1t - c0; }
             my_idx = idx1; my_c = c1; idx1 = idx2; c1 = c2;
         }
+        if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
         if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
         const double Ndoc = (double)(long long)wave_sum(csum);

@@ -13,14 +13,14 @@ namespace stm {
 
 constexpr int BT = 128;   // topics padded to 128
 
-inline size_t post_big_lds_doubles(int n, int MLD) { return (size_t)n * MLD + (size_t)BT * TLD + 4 * BT + 4 * TW; }
+inline size_t post_big_lds_doubles(int n, int MLD) { return (((size_t)n * MLD + 1) & ~(size_t)1) + (size_t)BT * TLD + 4 * BT + 4 * TW; }
 
 __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
     extern __shared__ __attribute__((aligned(16))) double big_lds[];
     const int lane = threadIdx.x;
     const int K = P.K, n = P.n, MLD = P.MLD;
     double *M = big_lds;                        // [n][MLD]: H, then A (upper) / L (lower) / R (upper)
-    double *T = M + (size_t)n * MLD;            // [BT][TLD] word tile, topic-major
+    double *T = M + (((size_t)n * MLD + 1) & ~(size_t)1);   // [BT][TLD] word tile, topic-major (16-byte aligned rows)
     double *sex = T + (size_t)BT * TLD;         // exp(eta~)
     double *sth = sex + BT;                     // stable_softmax(eta~)
     double *sdv = sth + BT;                     // eta - mu (dense siginv only)
@@ -40,6 +40,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
         double *bssT = P.beta_ssT + (size_t)asp * (size_t)P.V * K;
         const bool dump_phi = P.phi_out && doc == P.phi_doc;
+        long long tp[8];
+        tp[0] = P.prof ? (long long)__builtin_readcyclecounter() : 0;
 
         // ---- eta~, theta (unshifted softmax, stm.py:547-549), stable softmax, exp(eta~)
         double etav[2], muv[2], exv[2], thsv[2];
@@ -74,13 +76,16 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         for (int q = lane; q < BT * TLD; q += WAVE) T[q] = 0.0;
         __syncthreads();
 
+        if (P.prof) tp[1] = (long long)__builtin_readcyclecounter();
         double csum = 0.0, ll = 0.0, rowc[2] = {0.0, 0.0};
         bool bad = false;
         const int kc = (K + 3) >> 2;  // topics per quarter in the per-word sums (<= 32)
+        long long tq[5] = {0, 0, 0, 0, 0};
         for (int t0 = 0; t0 < Nd; t0 += TW) {
             const int nw = Nd - t0 < TW ? Nd - t0 : TW;
             const int my_idx = (lane < nw) ? P.indices[p0 + t0 + lane] : 0;
             const double my_c = (lane < nw) ? P.counts[p0 + t0 + lane] : 0.0;
+            long long c0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
             // -- 1. gather: coalesced beta rows, transposed into T[topic][word]
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 }
             }
             __syncthreads();
+            if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[0] += c1 - c0; c0 = c1; }
             // -- 2. per-word sums, lane = (word fr, topic quarter fq)
             {
                 double Sp = 0.0, Lp = 0.0;
@@ -112,6 +118,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 }
             }
             __syncthreads();
+            if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[1] += c1 - c0; c0 = c1; }
             // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -135,29 +142,46 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 }
             }
             __syncthreads();
-            // -- 4. H[:, j] += b b^T restricted to the tile, lane = column j (two columns per lane)
+            if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[2] += c1 - c0; c0 = c1; }
+            // -- 4. H[:, j] += b b^T restricted to the tile, lane = columns j0, j1; two rows i per round: the
+            // broadcast rows feed both column sets, and the four M elements are fetched with the rows.
+            // Lanes without a column work on the padding column n (MLD > n), so nothing here is predicated
+            // and the eight FMA chains interleave.
+            {
+                const int j0 = k0 < n ? k0 : n, j1 = k1 < n ? k1 : n;
+                double o0[TW], o1[TW];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int j = lane + WAVE * r;
-                if (j < n) {
-                    double own[TW];
+                for (int w = 0; w < TW; ++w) { o0[w] = T[(size_t)j0 * TLD + w]; o1[w] = T[(size_t)j1 * TLD + w]; }
+                for (int i = 0; i < n; i += 2) {
+                    const int i1 = i + 1 < n ? i + 1 : i;
+                    const double2 *ta = reinterpret_cast<const double2 *>(T + (size_t)i * TLD);
+                    const double2 *tb = reinterpret_cast<const double2 *>(T + (size_t)i1 * TLD);
+                    double2 va[TW / 2], vb[TW / 2];
 #pragma unroll
-                    for (int w = 0; w < TW; ++w) own[w] = T[(size_t)j * TLD + w];
-                    for (int i = 0; i < n; ++i) {
-                        const double2 *ti = reinterpret_cast<const double2 *>(T + (size_t)i * TLD);
-                        double s0 = 0.0, s1 = 0.0;
+                    for (int w = 0; w < TW / 2; ++w) { va[w] = ta[w]; vb[w] = tb[w]; }
+                    double *ma = M + (size_t)i * MLD, *mb = M + (size_t)i1 * MLD;
+                    const double m00 = ma[j0], m01 = ma[j1], m10 = mb[j0], m11 = mb[j1];
+                    double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0, r00 = 0.0, r01 = 0.0, r10 = 0.0, r11 = 0.0;
 #pragma unroll
-                        for (int w = 0; w < TW; w += 2) {
-                            const double2 v = ti[w >> 1];
-                            s0 = fma(v.x, own[w], s0);
-                            s1 = fma(v.y, own[w + 1], s1);
-                        }
-                        M[(size_t)i * MLD + j] += s0 + s1;
+                    for (int w = 0; w < TW / 2; ++w) {
+                        s00 = fma(va[w].x, o0[2 * w], s00); r00 = fma(va[w].y, o0[2 * w + 1], r00);
+                        s01 = fma(va[w].x, o1[2 * w], s01); r01 = fma(va[w].y, o1[2 * w + 1], r01);
+                        s10 = fma(vb[w].x, o0[2 * w], s10); r10 = fma(vb[w].y, o0[2 * w + 1], r10);
+                        s11 = fma(vb[w].x, o1[2 * w], s11); r11 = fma(vb[w].y, o1[2 * w + 1], r11);
+                    }
+                    ma[j0] = m00 + (s00 + r00);
+                    ma[j1] = m01 + (s01 + r01);
+                    if (i + 1 < n) {   // uniform
+                        mb[j0] = m10 + (s10 + r10);
+                        mb[j1] = m11 + (s11 + r11);
                     }
                 }
             }
             __syncthreads();
+            if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[3] += c1 - c0; c0 = c1; }
         }
+        if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
+        if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
@@ -179,6 +203,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         }
         __syncthreads();
 
+        if (P.prof) tp[3] = (long long)__builtin_readcyclecounter();
         // ---- PD ladder around one Cholesky (the upper triangle keeps A, L goes to the strict lower triangle)
         double diagA[2], Ldiag[2] = {1.0, 1.0};
 #pragma unroll
@@ -217,20 +242,21 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             bool ok = true;
             for (int j = 0; j < n; ++j) {
                 double t[2] = {0.0, 0.0};
+                {   // both row sets in one loop: the broadcast row j feeds two FMAs, twelve LDS reads in flight
+                    const double *r0 = M + (size_t)(k0 < n ? k0 : n - 1) * MLD, *r1 = M + (size_t)(k1 < n ? k1 : n - 1) * MLD;
+                    const double *rj = M + (size_t)j * MLD;
+                    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+                    int l = 0;
+                    for (; l + 3 < j; l += 4) {
+                        double x[4], y[4], pj[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int i = lane + WAVE * r;
-                    if (i < n && i >= j) {
-                        const double *ri = M + (size_t)i * MLD, *rj = M + (size_t)j * MLD;
-                        double a0 = 0.0, a1 = 0.0;
-                        int l = 0;
-                        for (; l + 1 < j; l += 2) {
-                            a0 = fma(ri[l], rj[l], a0);
-                            a1 = fma(ri[l + 1], rj[l + 1], a1);
-                        }
-                        if (l < j) a0 = fma(ri[l], rj[l], a0);
-                        t[r] = ((i == j) ? diagA[r] : rj[i]) - (a0 + a1);
+                        for (int q = 0; q < 4; ++q) { x[q] = r0[l + q]; y[q] = r1[l + q]; pj[q] = rj[l + q]; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { a[q] = fma(x[q], pj[q], a[q]); b[q] = fma(y[q], pj[q], b[q]); }
                     }
+                    for (; l < j; ++l) { const double pj = rj[l]; a[0] = fma(r0[l], pj, a[0]); b[0] = fma(r1[l], pj, b[0]); }
+                    if (k0 < n && k0 >= j) t[0] = ((k0 == j) ? diagA[0] : rj[k0]) - ((a[0] + a[1]) + (a[2] + a[3]));
+                    if (k1 < n && k1 >= j) t[1] = ((k1 == j) ? diagA[1] : rj[k1]) - ((b[0] + b[1]) + (b[2] + b[3]));
                 }
                 const double d = lane_bcast((j >> 6) ? t[1] : t[0], j & 63);
                 if (!(d > 0.0)) { ok = false; break; }
@@ -273,6 +299,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             }
         }
 
+        if (P.prof) tp[4] = (long long)__builtin_readcyclecounter();
         // ---- bound (stm.py:1068-1101)
         double dl = 0.0, q = 0.0;
 #pragma unroll
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         q = wave_sum(q);
         P.bound[doc] = ll + (-det) - 0.5 * q - P.sigmaentropy;
 
+        if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066): R = L^-T into the upper triangle
         double Rdiag[2];
 #pragma unroll
@@ -314,19 +342,32 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         if (!upper) {
             for (int i = n - 2; i >= 0; --i) {
                 double t[2] = {0.0, 0.0};
+                {   // both columns in one loop over the rows l of R below i (L[l][i] is a broadcast read)
+                    const int c0 = k0 < n ? k0 : n - 1, c1 = k1 < n ? k1 : n - 1;
+                    const double *ci = M + i, *p0 = M + c0, *p1 = M + c1;
+                    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+                    a[0] = M[(size_t)c0 * MLD + i] * Rdiag[0];   // the l == c terms
+                    b[0] = M[(size_t)c1 * MLD + i] * Rdiag[1];
+                    int l = i + 1;
+                    for (; l + 3 < n - 1; l += 4) {
+                        double u[4], x[4], y[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int c = lane + WAVE * r;
-                    if (c < n && c > i) {
-                        double a0 = M[(size_t)c * MLD + i] * Rdiag[r], a1 = 0.0;   // the l == c term
-                        int l = i + 1;
-                        for (; l + 1 < n - 1; l += 2) {
-                            a0 = fma(M[(size_t)l * MLD + i], (l < c) ? M[(size_t)l * MLD + c] : 0.0, a0);
-                            a1 = fma(M[(size_t)(l + 1) * MLD + i], (l + 1 < c) ? M[(size_t)(l + 1) * MLD + c] : 0.0, a1);
+                        for (int q = 0; q < 4; ++q) {
+                            u[q] = ci[(size_t)(l + q) * MLD]; x[q] = p0[(size_t)(l + q) * MLD]; y[q] = p1[(size_t)(l + q) * MLD];
                         }
-                        if (l < n - 1) a0 = fma(M[(size_t)l * MLD + i], (l < c) ? M[(size_t)l * MLD + c] : 0.0, a0);
-                        t[r] = -(a0 + a1);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            a[q] = fma(u[q], (l + q < c0) ? x[q] : 0.0, a[q]);
+                            b[q] = fma(u[q], (l + q < c1) ? y[q] : 0.0, b[q]);
+                        }
                     }
+                    for (; l < n - 1; ++l) {
+                        const double u = ci[(size_t)l * MLD];
+                        a[0] = fma(u, (l < c0) ? p0[(size_t)l * MLD] : 0.0, a[0]);
+                        b[0] = fma(u, (l < c1) ? p1[(size_t)l * MLD] : 0.0, b[0]);
+                    }
+                    if (k0 < n && k0 > i) t[0] = -((a[0] + a[1]) + (a[2] + a[3]));
+                    if (k1 < n && k1 > i) t[1] = -((b[0] + b[1]) + (b[2] + b[3]));
                 }
                 const double rii = srd[i];
 #pragma unroll
@@ -338,27 +379,57 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             }
         }
         __syncthreads();
-        // nu[i][j] = sum_{l >= max(i,j)} R[i][l] R[j][l], lane = column j; sigma_ss += nu (stm.py:582)
+        if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
+        // nu[i][j] = sum_{l >= max(i,j)} R[i][l] R[j][l], lane = columns j0, j1; sigma_ss += nu (stm.py:582).
+        // The diagonal of M is free by now (A's and L's diagonals live in registers): R[x][x] goes there so the
+        // loop has no special cases; row i of R is a broadcast read, rows j0 / j1 are the lane's own.
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = lane + WAVE * r;
-            if (j < n) {
-                for (int i = 0; i < n; ++i) {
-                    const int l0 = i > j ? i : j;
-                    double v = 0.0;
-                    if (upper) {
-                        v = (i == j) ? Rdiag[r] * Rdiag[r] : 0.0;
-                    } else {
-                        for (int l = l0; l < n; ++l) {
-                            const double ril = (l == i) ? srd[i] : M[(size_t)i * MLD + l];
-                            const double rjl = (l == j) ? Rdiag[r] : M[(size_t)j * MLD + l];
-                            v = fma(ril, rjl, v);
+        for (int r = 0; r < 2; ++r)
+            if (lane + WAVE * r < n) M[(size_t)(lane + WAVE * r) * MLD + lane + WAVE * r] = Rdiag[r];
+        __syncthreads();
+        {
+            const int j0 = k0 < n ? k0 : n - 1, j1 = k1 < n ? k1 : n - 1;
+            const double *q0 = M + (size_t)j0 * MLD, *q1 = M + (size_t)j1 * MLD;
+            for (int i = 0; i < n; ++i) {
+                double v0, v1;
+                if (upper) {
+                    v0 = (k0 == i) ? Rdiag[0] * Rdiag[0] : 0.0;
+                    v1 = (k1 == i) ? Rdiag[1] * Rdiag[1] : 0.0;
+                } else {
+                    const double *qi = M + (size_t)i * MLD;
+                    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+                    int l = i;
+                    for (; l + 3 < n; l += 4) {
+                        double u[4], x[4], y[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { u[q] = qi[l + q]; x[q] = q0[l + q]; y[q] = q1[l + q]; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            a[q] = fma(u[q], (l + q >= j0) ? x[q] : 0.0, a[q]);
+                            b[q] = fma(u[q], (l + q >= j1) ? y[q] : 0.0, b[q]);
                         }
                     }
-                    unsafeAtomicAdd(sig_acc + (size_t)i * n + j, v);
-                    if (P.nu_out) P.nu_out[(size_t)doc * n * n + (size_t)i * n + j] = v;
+                    for (; l < n; ++l) {
+                        const double u = qi[l];
+                        a[0] = fma(u, (l >= j0) ? q0[l] : 0.0, a[0]);
+                        b[0] = fma(u, (l >= j1) ? q1[l] : 0.0, b[0]);
+                    }
+                    v0 = (a[0] + a[1]) + (a[2] + a[3]);
+                    v1 = (b[0] + b[1]) + (b[2] + b[3]);
+                }
+                if (k0 < n) {
+                    unsafeAtomicAdd(sig_acc + (size_t)i * n + k0, v0);
+                    if (P.nu_out) P.nu_out[(size_t)doc * n * n + (size_t)i * n + k0] = v0;
+                }
+                if (k1 < n) {
+                    unsafeAtomicAdd(sig_acc + (size_t)i * n + k1, v1);
+                    if (P.nu_out) P.nu_out[(size_t)doc * n * n + (size_t)i * n + k1] = v1;
                 }
             }
+        }
+        if (P.prof && lane == 0) {
+            tp[7] = (long long)__builtin_readcyclecounter();
+            for (int q = 0; q < 7; ++q) P.prof[doc * 40 + 32 + q] = tp[q + 1] - tp[q];
         }
         __syncthreads();
     }

@@ -7,8 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from strutopy_amd import STM, _lib
 from strutopy_amd.corpus import synthetic_corpus
-syn = synthetic_corpus(20000, 10000, 50, n_words=150, seed=12345)
-m = STM(documents=syn.corpus, dictionary=None, content=False, K=50, X=syn.X, kappa_interactions=False, max_em_iter=2,
+ND, VV, KK = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (20000, 10000, 50)))   # docs V K
+syn = synthetic_corpus(ND, VV, KK, n_words=150, seed=12345)
+m = STM(documents=syn.corpus, dictionary=None, content=False, K=KK, X=syn.X, kappa_interactions=False, max_em_iter=2,
         sigma_prior=0, convergence_threshold=1e-9, init_type="random")
 for it in range(2):
     m._em_iteration_resident()
@@ -23,6 +24,8 @@ for it in range(2):
              "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "ZOOM_NEXT", "ACCEPT", "ACCEPT2", "FINISH"]
     pn = ["prologue", "word tiles", "sums", "H assembly", "Cholesky ladder", "bound", "inverse R", "nu MFMA"]
     print("   post kernel cycles/doc: " + ", ".join(f"{pn[q]} {out[:, 32 + q].mean():.0f}" for q in range(7)) + f", total {out[:, 32:39].sum(1).mean():.0f}")
+    if True:
+        print("   post tile phases cycles/doc: gather %.0f sums %.0f scatter %.0f H-acc %.0f" % tuple(out[:, 24:28].mean(0)))
     for i, nm in enumerate(names):
         c, v = out[:, 8 + i].mean(), out[:, 24 + i].mean()
         if v > 0:
