@@ -22,22 +22,33 @@ __global__ __launch_bounds__(256) void moments_kernel(const double *X, const dou
     const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
     const int64_t d0 = (int64_t)blockIdx.x * chunk;
     const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
+    // four documents in flight per thread (independent partial sums, fixed order)
+    auto sum4 = [&](auto term) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        int64_t d = d0;
+        for (; d + 3 < d1; d += 4) {
+            const double a = term(d), b = term(d + 1), c = term(d + 2), e = term(d + 3);
+            t0 += a; t1 += b; t2 += c; t3 += e;
+        }
+        for (; d < d1; ++d) t0 += term(d);
+        return (t0 + t1) + (t2 + t3);
+    };
     for (int slot = threadIdx.x; slot < L; slot += blockDim.x) {
         double t = 0.0;
         int s = slot;
         if (s == 0) {
             t = (double)(d1 > d0 ? d1 - d0 : 0);
         } else if ((s -= 1) < p) {
-            for (int64_t d = d0; d < d1; ++d) t += X[d * p + s];
+            t = sum4([&](int64_t d) { return X[d * p + s]; });
         } else if ((s -= p) < n) {
-            for (int64_t d = d0; d < d1; ++d) t += eta[d * n + s];
+            t = sum4([&](int64_t d) { return eta[d * n + s]; });
         } else if ((s -= n) < p * p) {
             const int a = s / p, b = s % p;
-            for (int64_t d = d0; d < d1; ++d) t += X[d * p + a] * X[d * p + b];
+            t = sum4([&](int64_t d) { return X[d * p + a] * X[d * p + b]; });
         } else {
             s -= p * p;
             const int a = s / n, i = s % n;
-            for (int64_t d = d0; d < d1; ++d) t += X[d * p + a] * eta[d * n + i];
+            t = sum4([&](int64_t d) { return X[d * p + a] * eta[d * n + i]; });
         }
         part[(size_t)blockIdx.x * L + slot] = t;
     }

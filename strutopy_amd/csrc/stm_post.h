@@ -663,13 +663,27 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     }
 }
 
-// out = sum over the replicated / per-block partial copies (fixed order)
-__global__ void reduce_sigma_kernel(const double *part, int nblocks, int nn, double *out) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nn) return;
-    double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += part[(size_t)b * nn + q];
-    out[q] = t;
+// out = sum over the replicated / per-block partial copies, in a fixed order: 64 slots per block, the copies
+// split over four 64-thread groups, four independent partial sums per thread, then a fixed combine
+__global__ __launch_bounds__(256) void reduce_sigma_kernel(const double *part, int nblocks, int nn, double *out) {
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + tx;
+    const int per = (nblocks + 3) >> 2;
+    const int b0 = ty * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    if (q < nn) {
+        int b = b0;
+        for (; b + 3 < b1; b += 4) {
+            const double a = part[(size_t)b * nn + q], c = part[(size_t)(b + 1) * nn + q];
+            const double d = part[(size_t)(b + 2) * nn + q], e = part[(size_t)(b + 3) * nn + q];
+            t0 += a; t1 += c; t2 += d; t3 += e;
+        }
+        for (; b < b1; ++b) t0 += part[(size_t)b * nn + q];
+    }
+    sh[ty][tx] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (ty == 0 && q < nn) out[q] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 
 // bound = np.sum(calculated_bounds) (stm.py:592): one block, fixed tree => deterministic
