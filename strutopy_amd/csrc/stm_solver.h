@@ -589,6 +589,8 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         // DCSRCH state (optimize/_dcsrch.py)
         ud stx, fx, gx, sty, fy, gy, stmin, stmax, width, width1, finit, ginit, gtest;
         int stage = 1, w1_calls = 0;
+        ud w1_a1, w1_f1;          // DCSRCH's first trial step and its function value (wolfe2 starts at the same step)
+        bool w1_have = false;
         bool brackt = false;
         // wolfe2 / zoom state (optimize/_linesearch.py)
         ud alpha0, alpha1, phi_a0, phi_a1, derphi_a0;
@@ -677,6 +679,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             } break;
             case S_W1_START: {  // scalar_search_wolfe1 + DCSRCH START
                 double a1;
+                w1_have = false;
                 if (derphi0 != 0) {
                     a1 = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
                     if (a1 < 0) a1 = 1.0;
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 ++w1_calls;
                 double stp = alpha;
                 const double f = fval, gd = dval;
+                if (w1_calls == 2) { w1_a1 = stp; w1_f1 = f; w1_have = true; }
                 const double ftest = finit + stp * gtest;
                 if (stage == 1 && f <= ftest && gd >= 0) stage = 2;
                 int task = 0;  // 0 FG, 1 CONVERGENCE, 2 WARNING
@@ -764,8 +768,14 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 else alpha1 = 1.0;
                 if (alpha1 < 0) alpha1 = 1.0;
                 alpha1 = py_min2(alpha1, amax);
-                alpha = alpha1; need_f = true; need_g = false; want_eval = true;
                 st = S_W2_FIRST;
+                if (w1_have && alpha1 == w1_a1) {
+                    // phi(alpha1) was DCSRCH's first evaluation (same x_k, p_k and step): scipy evaluates it
+                    // again and gets the same number
+                    fval = w1_f1; ++nfev;
+                    break;
+                }
+                alpha = alpha1; need_f = true; need_g = false; want_eval = true;
             } break;
             case S_W2_FIRST: {
                 phi_a1 = fval; phi_a0 = phi0; derphi_a0 = derphi0; w2_i = 0;
