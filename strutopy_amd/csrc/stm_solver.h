@@ -672,7 +672,15 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     for (int r = 0; r < VPL; ++r) p[r] = -t[r];
                 }
                 derphi0 = dot(g, p);
-                Lb = (sig_lmax + Ndoc) * dot(p, p);
+                {   // Lipschitz bound of phi'(s) = df(x + s p).p along this direction (see S_W1_ITER):
+                    // p^T [siginv + N_d (diag(theta) - theta theta^T)] p = p^T siginv p + N_d Var_theta([p, 0])
+                    //   <= lambda_max(siginv) |p|^2 + N_d (max [p, 0] - min [p, 0])^2 / 4     for every theta
+                    double hi = 0.0, lo = 0.0;
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) { hi = nanmax(hi, p[r]); lo = nanmax(lo, -p[r]); }
+                    const double range = wave_nanmax(hi) + wave_nanmax(lo);
+                    Lb = sig_lmax * dot(p, p) + Ndoc * (0.25 * (range * range));
+                }
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
                 st = S_W1_START;
@@ -751,8 +759,9 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 // Outcome-preserving shortcut for the tail of a failing search.  Once the minimiser is
                 // bracketed every later trial step lies in [0, smax], smax = max(stx, sty) (the interval
                 // only shrinks; an out-of-range step is replaced by stx).  phi'(s) = df(x + s p).p has
-                // |phi'(s) - phi'(0)| <= s (lambda_max(siginv) + N_d) |p|^2 =: s Lb  (the Jacobian of
-                // df is siginv + N_d (diag(theta) - theta theta^T), eigenvalues <= lambda_max + N_d).
+                // 0 <= phi'(s) - phi'(0) <= s Lb: the Jacobian of df is siginv + N_d (diag(theta) - theta theta^T),
+                // whose quadratic form in p is p^T siginv p plus N_d times the variance of [p, 0] under theta,
+                // at most a quarter of its squared range whatever theta is (Lb is set in S_OUTER_TOP).
                 // DCSRCH reports convergence only if |phi'(s)| <= 0.9 |phi'(0)|, impossible while
                 // smax Lb < 0.1 |phi'(0)| (tested with a 2x margin for the rounding of phi').  What
                 // remains is ~60 evaluations inside rounding noise that can only end in a WARNING or
