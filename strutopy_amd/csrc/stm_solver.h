@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         int k = 0, status = 0;
         bool H_ident = true;
         // line-search shared
-        ud phi0, old_phi0, derphi0, Lb;
+        ud phi0, old_phi0, derphi0, Lb, Lv, prange;
         const ud sig_lmax = P.sig_bound;
         // DCSRCH state (optimize/_dcsrch.py)
         ud stx, fx, gx, sty, fy, gy, stmin, stmax, width, width1, finit, ginit, gtest;
@@ -672,14 +672,40 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     for (int r = 0; r < VPL; ++r) p[r] = -t[r];
                 }
                 derphi0 = dot(g, p);
-                {   // Lipschitz bound of phi'(s) = df(x + s p).p along this direction (see S_W1_ITER):
-                    // p^T [siginv + N_d (diag(theta) - theta theta^T)] p = p^T siginv p + N_d Var_theta([p, 0])
-                    //   <= lambda_max(siginv) |p|^2 + N_d (max [p, 0] - min [p, 0])^2 / 4     for every theta
-                    double hi = 0.0, lo = 0.0;
+                {   // Lipschitz bounds of phi'(s) = df(x + s p).p along this direction (see S_W1_ITER):
+                    //   phi''(s) = p^T [siginv + N_d (diag(theta_s) - theta_s theta_s^T)] p = p^T siginv p + N_d Var_{theta_s}([p, 0])
+                    // (a) Var <= (max [p, 0] - min [p, 0])^2 / 4 for every theta                       -> Lb
+                    // (b) theta_s(i) <= theta_0(i) exp(s range) (|d log theta_s(i) / ds| <= range), hence
+                    //     Var_{theta_s} <= E_{theta_s}[(p~ - c)^2] <= exp(s range) Var_{theta_0},  c = E_{theta_0} p~   -> Lv (1 + t + t^2), t = s range <= 1
+                    double hi = 0.0, lo = 0.0, mx = 0.0;
 #pragma unroll
-                    for (int r = 0; r < VPL; ++r) { hi = nanmax(hi, p[r]); lo = nanmax(lo, -p[r]); }
+                    for (int r = 0; r < VPL; ++r) {
+                        hi = nanmax(hi, p[r]); lo = nanmax(lo, -p[r]);
+                        if (lane + WAVE * r < n) mx = nanmax(mx, x[r]);
+                    }
                     const double range = wave_nanmax(hi) + wave_nanmax(lo);
-                    Lb = sig_lmax * dot(p, p) + Ndoc * (0.25 * (range * range));
+                    const double pp = dot(p, p);
+                    Lb = sig_lmax * pp + Ndoc * (0.25 * (range * range));
+                    prange = range;
+                    const double m = wave_nanmax(mx);   // max of [x, 0]
+                    double e[VPL], z = 0.0, e1 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) {
+                        e[r] = (lane + WAVE * r < n) ? exp(x[r] - m) : 0.0;
+                        z += e[r]; e1 += e[r] * p[r];
+                    }
+                    const double eK = exp(-m);          // the appended topic: p~ = 0
+                    const double Z = wave_sum(z) + eK, c = wave_sum(e1) / Z;
+                    double v2 = 0.0, psp = 0.0;
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) {
+                        const double dv = p[r] - c;
+                        v2 += e[r] * (dv * dv);
+                        if (sdiag && lane + WAVE * r < n) psp += (p[r] * sd[r]) * p[r];
+                    }
+                    const double var0 = (wave_sum(v2) + eK * (c * c)) / Z;
+                    const double quad = sdiag ? wave_sum(psp) : sig_lmax * pp;
+                    Lv = (quad + Ndoc * var0) * (1.0 + 1e-9);
                 }
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
@@ -767,7 +793,11 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 // remains is ~60 evaluations inside rounding noise that can only end in a WARNING or
                 // the 100-call cap, i.e. alpha = None and the hand-over to wolfe2, whose start does
                 // not depend on DCSRCH's final state.
-                if (brackt && py_max2(stx, sty) * Lb <= 0.05 * -derphi0) { st = S_W2_START; break; }
+                if (brackt) {
+                    const double smax = py_max2(stx, sty), tr = smax * prange;
+                    const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
+                    if (smax * Ls <= 0.05 * -derphi0) { st = S_W2_START; break; }
+                }
                 alpha = stp; need_f = true; need_g = true; want_eval = true;
                 st = S_W1_ITER;
             } break;
@@ -833,7 +863,11 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 // same bound as in S_W1_ITER: every later a_j lies between a_lo and a_hi, and zoom accepts
                 // only when |phi'(a_j)| <= 0.9 |phi'(0)|; if that is out of reach the remaining iterations
                 // can only exhaust maxiter = 10 -> _LineSearchError -> status 2 with x unchanged
-                if (py_max2(a_lo, a_hi) * Lb <= 0.05 * -derphi0 && a_lo >= 0 && a_hi >= 0) { status = 2; st = S_FINISH; break; }
+                if (a_lo >= 0 && a_hi >= 0) {
+                    const double smax = py_max2(a_lo, a_hi), tr = smax * prange;
+                    const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
+                    if (smax * Ls <= 0.05 * -derphi0) { status = 2; st = S_FINISH; break; }
+                }
                 const double dalpha = a_hi - a_lo;
                 double a, b;
                 if (dalpha < 0) { a = a_hi; b = a_lo; } else { a = a_lo; b = a_hi; }
