@@ -604,6 +604,21 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         bool want_eval = true, need_f = true, need_g = true;
         bool have_x = false, f_ok = false, g_ok = false;
         int st = S_INIT_DONE;
+        // Second outcome-preserving test for a failing search, on the objective itself.  f along the ray has
+        //   f''(s) = p^T siginv p + N_d Var_{theta_s}(p~) - sum_w c_w Var_{q_w,s}(p~) <= U   on [0, b]
+        // (U as in S_OUTER_TOP; the data term only lowers it).  With f(0) and a rejected f(b) known, the chord
+        // bound f(s) >= f(0) + s (f(b) - f(0)) / b - U s (b - s) / 2 shows that the sufficient-decrease test
+        // f(s) <= f(0) + c1 s phi'(0), which DCSRCH and _zoom both require of an accepted step, fails on all of
+        // (0, b) when (f(b) - f(0)) / b + c1 |phi'(0)| > U b / 2.  Below s_lo = 0.05 |phi'(0)| / U the curvature test
+        // is out of reach (first cut); above it the violation s * margin must dwarf the rounding of f.
+        auto armijo_dead = [&](double b, double phi_b) __attribute__((always_inline)) -> bool {
+            const double tr = b * prange;
+            const double U = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
+            const double slope0 = -derphi0;
+            const double margin = (phi_b - phi0) / b + c1 * slope0 - 0.5 * U * b;
+            const double s_lo = 0.05 * slope0 / U;
+            return slope0 > 0.0 && margin > 0.0 && s_lo * margin >= 1e-9 * py_max2(1.0, fabs((double)phi0));
+        };
 
         if (P.debug_flags & 1) st = S_FINISH;
         long guard = 0;
@@ -797,6 +812,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     const double smax = py_max2(stx, sty), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
                     if (smax * Ls <= 0.05 * -derphi0) { st = S_W2_START; break; }
+                    if (stx == 0.0 && sty > 0.0 && armijo_dead(sty, fy)) { st = S_W2_START; break; }
                 }
                 alpha = stp; need_f = true; need_g = true; want_eval = true;
                 st = S_W1_ITER;
@@ -867,6 +883,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     const double smax = py_max2(a_lo, a_hi), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
                     if (smax * Ls <= 0.05 * -derphi0) { status = 2; st = S_FINISH; break; }
+                    if (a_lo == 0.0 && a_hi > 0.0 && armijo_dead(a_hi, phi_hi)) { status = 2; st = S_FINISH; break; }
                 }
                 const double dalpha = a_hi - a_lo;
                 double a, b;
