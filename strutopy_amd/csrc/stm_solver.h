@@ -212,8 +212,8 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
     // wave 0 <-> wave 1 mailbox (NW = 2)
     __shared__ double xch_xt[NW == 2 ? WAVE : 1];   // trial point
     __shared__ double xch_gv[NW == 2 ? WAVE : 1];   // df at the trial point / partial g0
-    __shared__ double xch_res[8];                   // [0] data-term share, [1] quadratic form, [2] m, [4..5] word-count shares
-    __shared__ int xch_cmd[4];                      // [0] request bits (1 f, 2 g, 4 exit), [1..2] bad-beta flags
+    __shared__ double xch_res[8];                   // [0] data-term share, [1] quadratic form, [2] m, [4..5] word-count shares, [6..7] rho, cc of a BFGS update
+    __shared__ int xch_cmd[4];                      // [0] request bits (1 f, 2 g, 4 exit, 8 BFGS update (16: from the identity)), [1..2] bad-beta flags
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = NW == 2 ? (int)(threadIdx.x >> 6) : 0;
     const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
@@ -491,6 +491,31 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             }
         };
 
+        // rows [i0, i1) of column j of the BFGS update  H <- H - rho (s w^T + w s^T) + cc s s^T  (see S_ACCEPT2).
+        // Rows are independent, but the compiler cannot prove that a later row's load does not alias an earlier
+        // row's store: fetch four rows, then store four (LDS latency paid once per batch).
+        auto bfgs_rows = [&](int j, int i0, int i1, bool ident, double rhok, double cc, double sj, double wj) __attribute__((always_inline)) {
+            double *hp = Hs + j;
+            int i = i0;
+            for (; i + 3 < i1; i += 4) {
+                double h[4], si[4], wi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[q] = ident ? (i + q == j ? 1.0 : 0.0) : hp[(size_t)(i + q) * n];
+                    si[q] = sv[i + q]; wi[q] = sw[i + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    hp[(size_t)(i + q) * n] = h[q] - rhok * (si[q] * wj + wi[q] * sj) + cc * (si[q] * sj);
+            }
+            for (; i < i1; ++i) {
+                const double h = ident ? (i == j ? 1.0 : 0.0) : hp[(size_t)i * n];
+                const double si = sv[i], wi = sw[i];
+                hp[(size_t)i * n] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
+            }
+        };
+        const int nh = NW == 2 ? ((n / 2 + 3) & ~3) : n;   // two-wave form: wave 0 updates rows [0, nh), wave 1 the rest
+
         // ---- two-wave form: wave 1 serves evaluation requests until wave 0 posts "exit"
         if (NW == 2) {
             // df needs the data term g0 of ALL words: wave 0 hands its share to wave 1
@@ -502,6 +527,11 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     __syncthreads();  // (0) request posted: xch_cmd[0] and the trial point
                     const int cmd = uni(xch_cmd[0]);
                     if (cmd & 4) break;
+                    if (cmd & 8) {   // its half of a BFGS matrix update (s, w in sv / sw; rho, cc in the mailbox)
+                        if (lane < n) bfgs_rows(lane, nh < n ? nh : n, n, (cmd & 16) != 0, uni(xch_res[6]), uni(xch_res[7]), sv[lane], sw[lane]);
+                        __syncthreads();  // (u) update complete
+                        continue;
+                    }
                     xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
                     // while wave 0 works on max / exp(eta~ - m): the pieces that do not need them
                     double q = 0.0;
@@ -970,35 +1000,20 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
                     if (lane + WAVE * r < n) { sv[lane + WAVE * r] = s[r]; sw[lane + WAVE * r] = w[r]; }
-                STM_WAVE_SYNC();
+                if (NW == 2) {
+                    if (lane == 0) { xch_res[6] = rhok; xch_res[7] = cc; xch_cmd[0] = 8 | (H_ident ? 16 : 0); }
+                    __syncthreads();   // (0) wave 1 takes rows [nh, n)
+                    if (lane < n) bfgs_rows(lane, 0, nh < n ? nh : n, H_ident, rhok, cc, s[0], w[0]);
+                    __syncthreads();   // (u)
+                } else {
+                    STM_WAVE_SYNC();
 #pragma unroll
-                for (int r = 0; r < VPL; ++r) {
-                    const int j = lane + WAVE * r;
-                    if (j < n) {
-                        const double sj = s[r], wj = w[r];
-                        // rows are independent, but the compiler cannot prove that a later row's load does not
-                        // alias an earlier row's store: fetch four rows, then store four (LDS latency paid once per batch)
-                        double *hp = Hs + j;
-                        int i = 0;
-                        for (; i + 3 < n; i += 4) {
-                            double h[4], si[4], wi[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                h[q] = H_ident ? (i + q == j ? 1.0 : 0.0) : hp[(size_t)(i + q) * n];
-                                si[q] = sv[i + q]; wi[q] = sw[i + q];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                hp[(size_t)(i + q) * n] = h[q] - rhok * (si[q] * wj + wi[q] * sj) + cc * (si[q] * sj);
-                        }
-                        for (; i < n; ++i) {
-                            const double h = H_ident ? (i == j ? 1.0 : 0.0) : hp[(size_t)i * n];
-                            const double si = sv[i], wi = sw[i];
-                            hp[(size_t)i * n] = h - rhok * (si * wj + wi * sj) + cc * (si * sj);
-                        }
+                    for (int r = 0; r < VPL; ++r) {
+                        const int j = lane + WAVE * r;
+                        if (j < n) bfgs_rows(j, 0, n, H_ident, rhok, cc, s[r], w[r]);
                     }
+                    STM_WAVE_SYNC_MEM();
                 }
-                STM_WAVE_SYNC_MEM();
                 H_ident = false;
                 st = S_OUTER_TOP;
             } break;
