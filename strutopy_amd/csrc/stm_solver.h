@@ -599,8 +599,15 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 const int i = lane + WAVE * r;
                 double t = 0.0;
                 if (i < n) {   // the sum stays in order (H g must round like scipy's dot up to reassociation-free parts)
-#pragma unroll 4
-                    for (int j = 0; j < n; ++j) t += Hs[(size_t)j * n + i] * sv[j];
+                    int j = 0;
+                    for (; j + 7 < n; j += 8) {   // sixteen LDS reads in flight, the additions stay in order
+                        double hv[8], vv[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { hv[q] = Hs[(size_t)(j + q) * n + i]; vv[q] = sv[j + q]; }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) t += hv[q] * vv[q];
+                    }
+                    for (; j < n; ++j) t += Hs[(size_t)j * n + i] * sv[j];
                 }
                 out[r] = t;
             }
