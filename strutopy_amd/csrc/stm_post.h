@@ -366,7 +366,21 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD, *rk = rj + MLD;
                     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
                     int l = 0;
-                    for (; l + 3 < j; l += 4) {   // six 16-byte LDS reads in flight per round (rows are 16-byte aligned)
+                    for (; l + 7 < j; l += 8) {   // twelve 16-byte LDS reads in flight per round (rows are 16-byte aligned)
+                        double2 xv[4], pv[4], qv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            xv[u] = *reinterpret_cast<const double2 *>(ri + l + 2 * u);
+                            pv[u] = *reinterpret_cast<const double2 *>(rj + l + 2 * u);
+                            qv[u] = *reinterpret_cast<const double2 *>(rk + l + 2 * u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a0 = fma(xv[u].x, pv[u].x, a0); b0 = fma(xv[u].x, qv[u].x, b0);
+                            a1 = fma(xv[u].y, pv[u].y, a1); b1 = fma(xv[u].y, qv[u].y, b1);
+                        }
+                    }
+                    for (; l + 3 < j; l += 4) {   // six 16-byte LDS reads in flight per round
                         const double2 xa = *reinterpret_cast<const double2 *>(ri + l), xb = *reinterpret_cast<const double2 *>(ri + l + 2);
                         const double2 pa = *reinterpret_cast<const double2 *>(rj + l), pb = *reinterpret_cast<const double2 *>(rj + l + 2);
                         const double2 qa = *reinterpret_cast<const double2 *>(rk + l), qb = *reinterpret_cast<const double2 *>(rk + l + 2);
