@@ -208,16 +208,16 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 }
                 Sp += __shfl_xor(Sp, 16); Sp += __shfl_xor(Sp, 32);
                 Lp += __shfl_xor(Lp, 16); Lp += __shfl_xor(Lp, 32);
-                if (lane < nw) {   // quarter 0 owns the word
-                    const double c = my_c;
-                    const double sq = sqrt(c);
-                    ll += log_pos(Lp) * c;
-                    csum += c;
-                    double *wp = wpar + 4 * lane;
-                    wp[0] = sq;
-                    wp[1] = Sp;
-                    wp[2] = 1.0 / Sp;
-                    wp[3] = sq / Sp;      // update_z: sqrt(c) / colsum, stm.py:1115
+                if (lane < TW) {   // quarter 0 owns the word; words beyond the document get { 0, 0 }
+                    double wq = 0.0, sq = 0.0;
+                    if (lane < nw) {
+                        const double c = my_c;
+                        sq = sqrt(c);
+                        ll += log_pos(Lp) * c;
+                        csum += c;
+                        wq = sq / Sp;     // sqrt(c) / colsum: update_z, stm.py:1115, and the factor of b, stm.py:1001
+                    }
+                    *reinterpret_cast<double2 *>(wpar + 2 * lane) = make_double2(wq, sq);
                 }
             }
             STM_POST_SYNC();
@@ -225,31 +225,29 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
             // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
             if (isk) {
                 double *trow = T + (size_t)lane * TLD;
-                // four words per round: their LDS reads are issued together, the tail is masked
+                // four words per round, their LDS traffic in 16-byte pieces; columns beyond the document hold
+                // zeros and get zeros back.  b = a * (sqrt(c) / S) serves both the Hessian (stm.py:1001, which
+                // divides a * sqrt(c) by S: <= 1.5 ulp apart) and phi = b * sqrt(c) (stm.py:1115-1116, this order);
+                // rowsum(c') of stm.py:1002,1011 is the row sum of that same product.
                 for (int j0 = 0; j0 < nw; j0 += 4) {
-                    double tv[4], sq[4], Sj[4], rj[4], wj[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = j0 + u < nw ? j0 + u : nw - 1;
-                        tv[u] = trow[j];
-                        sq[u] = wpar[4 * j]; Sj[u] = wpar[4 * j + 1]; rj[u] = wpar[4 * j + 2]; wj[u] = wpar[4 * j + 3];
-                    }
+                    double2 *tp2 = reinterpret_cast<double2 *>(trow + j0);
+                    const double2 ta = tp2[0], tb = tp2[1];
+                    const double2 *wp2 = reinterpret_cast<const double2 *>(wpar + 2 * j0);
+                    const double2 w0 = wp2[0], w1 = wp2[1], w2 = wp2[2], w3 = wp2[3];   // { sqrt(c) / S, sqrt(c) }
+                    const double b0 = (ta.x * ex) * w0.x, b1 = (ta.y * ex) * w1.x;
+                    const double b2 = (tb.x * ex) * w2.x, b3 = (tb.y * ex) * w3.x;
+                    const double ph[4] = {b0 * w0.y, b1 * w1.y, b2 * w2.y, b3 * w3.y};
+                    tp2[0] = make_double2(b0, b1);
+                    tp2[1] = make_double2(b2, b3);
+                    rowc += ph[0]; rowc += ph[1]; rowc += ph[2]; rowc += ph[3];
+                    bad |= !(ph[0] >= 0.0) | !(ph[1] >= 0.0) | !(ph[2] >= 0.0) | !(ph[3] >= 0.0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int j = j0 + u;
                         if (j < nw) {   // uniform
                             const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                            const double a = tv[u] * ex;
-                            // b = a*sqrt(c)/S (stm.py:1001): quotient by the shared divisor from its reciprocal
-                            const double num = a * sq[u];
-                            const double q0 = num * rj[u];
-                            const double b = fma(fma(-q0, Sj[u], num), rj[u], q0);
-                            const double phi = a * wj[u] * sq[u];   // stm.py:1115-1116
-                            bad |= !(phi >= 0.0);
-                            rowc += b * sq[u];                  // rowsum(c'), c' = b*sqrt(c), stm.py:1002,1011
-                            trow[j] = b;
-                            if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, phi);  // stm.py:588
-                            if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = phi;
+                            if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, ph[u]);  // stm.py:588
+                            if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = ph[u];
                         }
                     }
                 }
