@@ -18,7 +18,8 @@
 //               only, accumulated in registers over all tiles of the document
 // The (K-1)^2 matrix then lives in one LDS array M (aliasing T): Cholesky overwrites the strict
 // lower triangle with L, the untouched upper triangle still holds A for the make_pd fallbacks,
-// and R = L^-T later overwrites the upper triangle.  nu = R R^T = H^-1 is again a Gram product
+// and X = L^-1 then takes L's place (16 x 16 diagonal blocks by substitution, the blocks below them
+// on the matrix cores).  nu = X^T X = H^-1 is again a Gram product
 // and is accumulated ON THE MATRIX CORES ACROSS ALL DOCUMENTS of the workgroup
 // (sigma_ss = sum_d R_d R_d^T); one atomic flush per workgroup at the end of the launch.
 #pragma once
@@ -519,80 +520,121 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066)
         const double Rdiag = 1.0 / Ldiag;
         if (isn) srd[lane] = Rdiag;
+        STM_POST_SYNC();
+        long long ti[4] = {0, 0, 0, 0};
+        if (P.prof) ti[0] = (long long)__builtin_readcyclecounter();
         if (!upper) {
-            // R = U^{-1}, U = L^T: column c in lane c, rows from the bottom up, TWO rows (i, i-1) per step: both
-            // sums run over the same rows l of R (one load of R[l][lane] feeds two FMAs), row i-1's extra term
-            // takes R[i][lane] from the register it was just computed in.  R overwrites the upper triangle.
-            int i = n - 2;
-            for (; i >= 1; i -= 2) {
-                double tI = 0.0, tH = 0.0;   // rows i and i - 1
-                if (isn && lane >= i) {
-                    const double *ci = M + i, *ch = M + i - 1, *cl = M + lane;
-                    // l == lane terms: L[lane][i] R[lane][lane], L[lane][i-1] R[lane][lane]
-                    double i0 = (lane > i) ? M[(size_t)lane * MLD + i] * Rdiag : 0.0, i1 = 0.0;
-                    double h0 = M[(size_t)lane * MLD + i - 1] * Rdiag, h1 = 0.0;
-                    int l = i + 1;
-                    for (; l + 3 < n - 1; l += 4) {   // twelve LDS reads in flight per round
-                        const double v0 = cl[(size_t)l * MLD], v1 = cl[(size_t)(l + 1) * MLD];
-                        const double v2 = cl[(size_t)(l + 2) * MLD], v3 = cl[(size_t)(l + 3) * MLD];
-                        const double p0 = ci[(size_t)l * MLD], p1 = ci[(size_t)(l + 1) * MLD];
-                        const double p2 = ci[(size_t)(l + 2) * MLD], p3 = ci[(size_t)(l + 3) * MLD];
-                        const double q0 = ch[(size_t)l * MLD], q1 = ch[(size_t)(l + 1) * MLD];
-                        const double q2 = ch[(size_t)(l + 2) * MLD], q3 = ch[(size_t)(l + 3) * MLD];
-                        const double r0 = (l < lane) ? v0 : 0.0, r1 = (l + 1 < lane) ? v1 : 0.0;
-                        const double r2 = (l + 2 < lane) ? v2 : 0.0, r3 = (l + 3 < lane) ? v3 : 0.0;
-                        i0 = fma(p0, r0, i0); h0 = fma(q0, r0, h0);
-                        i1 = fma(p1, r1, i1); h1 = fma(q1, r1, h1);
-                        i0 = fma(p2, r2, i0); h0 = fma(q2, r2, h0);
-                        i1 = fma(p3, r3, i1); h1 = fma(q3, r3, h1);
+            // X = L^-1 (so that nu = X^T X), blocked by 16 and IN PLACE of L: lower triangle and diagonal of M.
+            // (I) the diagonal blocks, all at once, lane = (block, column c): X[i][c] = -(sum_{c<=l<i} L[i][l] X[l][c]) / L[i][i]
+            //     row by row and in place; a lane only ever reads back its own column, so the steps need no hand-off.
+            {
+                const int c = lane & 15, base = lane & ~15;
+                const int rows = n - base < 16 ? n - base : 16;    // rows of this lane's block (<= 0: no block)
+                const int rb = base < n ? base : 0;                 // lanes beyond the matrix shadow block 0 (nothing is stored)
+                const int rlast = (rows > 0 ? rows : 16) - 1;
+                double *xc = M + (size_t)rb * MLD + (base < n ? lane : c);   // X[rb + l][column]: the lane's own column, in place
+                if (base < n && c < rows) xc[(size_t)c * MLD] = srd[lane];  // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
+                // every step fetches its whole row of L (broadcast per block) and the whole column of X in one batch --
+                // one LDS round trip per step -- and masks the terms outside [c, i)
+#pragma unroll 1
+                for (int i = 1; i < 16; ++i) {
+                    const int ir = i < rlast ? i : rlast;           // clamped: reads stay inside the matrix
+                    const double *lrow = M + (size_t)(rb + ir) * MLD + rb;
+                    double lv[16], xv[16];
+#pragma unroll
+                    for (int l = 0; l < 16; l += 2) {
+                        const double2 t = *reinterpret_cast<const double2 *>(lrow + l);
+                        lv[l] = t.x; lv[l + 1] = t.y;
+                        xv[l] = xc[(size_t)(l < rlast ? l : rlast) * MLD];
+                        xv[l + 1] = xc[(size_t)(l + 1 < rlast ? l + 1 : rlast) * MLD];
                     }
-                    for (; l + 1 < n - 1; l += 2) {
-                        const double r0 = (l < lane) ? cl[(size_t)l * MLD] : 0.0;
-                        const double r1 = (l + 1 < lane) ? cl[(size_t)(l + 1) * MLD] : 0.0;
-                        i0 = fma(ci[(size_t)l * MLD], r0, i0);
-                        h0 = fma(ch[(size_t)l * MLD], r0, h0);
-                        i1 = fma(ci[(size_t)(l + 1) * MLD], r1, i1);
-                        h1 = fma(ch[(size_t)(l + 1) * MLD], r1, h1);
+                    const double rd = srd[rb + ir];
+                    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 16; l += 2) {
+                        t0 = fma(lv[l], (l >= c && l < i) ? xv[l] : 0.0, t0);
+                        t1 = fma(lv[l + 1], (l + 1 >= c && l + 1 < i) ? xv[l + 1] : 0.0, t1);
                     }
-                    if (l < n - 1) {
-                        const double r0 = (l < lane) ? cl[(size_t)l * MLD] : 0.0;
-                        i0 = fma(ci[(size_t)l * MLD], r0, i0);
-                        h0 = fma(ch[(size_t)l * MLD], r0, h0);
-                    }
-                    tI = i0 + i1;
-                    tH = h0 + h1;
+                    // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
+                    if (base < n && i > c && i < rows) xc[(size_t)i * MLD] = -(t0 + t1) * rd;
                 }
-                const double rii = lane_bcast(Rdiag, i), rhh = lane_bcast(Rdiag, i - 1);
-                const double lih = uni(M[(size_t)i * MLD + i - 1]);                 // L[i][i-1]
-                const double Ri = (isn && lane > i) ? -tI * rii : 0.0;              // R[i][lane]
-                // row i-1: the l == i term L[i][i-1] R[i][lane] for lane > i (lane == i carried it as its l == lane term)
-                const double tH2 = (lane > i) ? tH + lih * Ri : tH;
-                if (isn && lane > i) M[(size_t)i * MLD + lane] = Ri;
-                if (isn && lane > i - 1) M[(size_t)(i - 1) * MLD + lane] = -tH2 * rhh;
-                STM_POST_SYNC();
             }
-            if (i == 0) {   // a single row left
-                double t = 0.0;
-                if (isn && lane > 0) {
-                    const double *cl = M + lane;
-                    double t0 = M[(size_t)lane * MLD] * Rdiag, t1 = 0.0;
-                    int l = 1;
-                    for (; l + 1 < n - 1; l += 2) {
-                        t0 = fma(M[(size_t)l * MLD], (l < lane) ? cl[(size_t)l * MLD] : 0.0, t0);
-                        t1 = fma(M[(size_t)(l + 1) * MLD], (l + 1 < lane) ? cl[(size_t)(l + 1) * MLD] : 0.0, t1);
+            STM_POST_SYNC();
+            if (P.prof) ti[1] = (long long)__builtin_readcyclecounter();
+            // (II) X_ij = -X_ii (sum_{j<=k<i} L_ik X_kj) on the matrix cores, block columns left to right, block rows
+            //      top down (X_ij takes the place of L_ij, which no later product reads).  The inner sum comes out
+            //      of the MFMA in exactly the register layout its B operand wants, so it never visits the LDS.
+            {
+                // runtime loops on purpose (the kernel lives at its VGPR budget): four fragment pairs in flight per step;
+                // loads are unconditional on clamped rows, masks are applied to the loaded values
+                const int nm1 = n - 1;
+#pragma unroll 1
+                for (int bj = 0; bj + 1 < NB; ++bj) {
+#pragma unroll 1
+                    for (int bi = bj + 1; bi < NB; ++bi) {
+                        const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
+                        const double *arow = M + (size_t)arc * MLD;           // row of L_i* / X_ii for the A operands
+                        const int bc = bj * 16 + fr;
+                        v4d sacc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                        for (int k = bj; k < bi; ++k) {
+                            double av[4], bv[4];
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) {
+                                const int kk = k * 16 + 4 * sk + fq;           // < 16 (NB - 1) <= n: full blocks only
+                                av[sk] = arow[kk];                              // L_ik[fr][4 sk + fq]
+                                bv[sk] = M[(size_t)kk * MLD + bc];              // X_kj[4 sk + fq][fr]
+                            }
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) {
+                                const int kk = k * 16 + 4 * sk + fq;
+                                const double a = (ar < n) ? av[sk] : 0.0;
+                                const double bb = (k > bj || bc <= kk) ? bv[sk] : 0.0;   // the diagonal block of X is lower triangular
+                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, sacc, 0, 0, 0);
+                            }
+                        }
+                        double xv[4];
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) {
+                            const int ac = bi * 16 + 4 * sk + fq;
+                            xv[sk] = arow[ac < n ? ac : nm1];                   // X_ii[fr][4 sk + fq]
+                        }
+                        v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) {
+                            const int ac = bi * 16 + 4 * sk + fq;
+                            const double a = (ac <= ar && ar < n) ? xv[sk] : 0.0;
+                            dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sacc[sk], dacc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = bi * 16 + fq + 4 * r;
+                            if (row < n) M[(size_t)row * MLD + bc] = -dacc[r];
+                        }
+                        STM_POST_SYNC();
                     }
-                    if (l < n - 1) t0 = fma(M[(size_t)l * MLD], (l < lane) ? cl[(size_t)l * MLD] : 0.0, t0);
-                    t = -(t0 + t1);
                 }
-                const double r00 = lane_bcast(Rdiag, 0);
-                if (isn && lane > 0) M[lane] = t * r00;
-                STM_POST_SYNC();
+            }
+            if (P.prof) ti[2] = (long long)__builtin_readcyclecounter();
+            if (REM) {   // (III) the row beyond the blocks: X[R0][j] = -X[R0][R0] sum_{j<=k<R0} L[R0][k] X[k][j], lane = column j
+                double t[4] = {0.0, 0.0, 0.0, 0.0};
+                const double *lr = M + (size_t)R0 * MLD, *xc = M + (lane < R0 ? lane : 0);
+                for (int k = 0; k < R0; k += 8) {
+                    double lv[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { lv[u] = lr[k + u]; xv[u] = xc[(size_t)(k + u) * MLD]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u & 3] = fma(lv[u], (k + u >= lane) ? xv[u] : 0.0, t[u & 3]);
+                }
+                const double xr = -((t[0] + t[1]) + (t[2] + t[3])) * srd[R0];
+                if (lane < R0) M[(size_t)R0 * MLD + lane] = xr;   // after every lane's reads of row R0 (one instruction stream)
             }
         }
         STM_POST_SYNC();
         if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
-        // nu = R R^T on the matrix cores, accumulated straight into the workgroup's running sum
-        // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq], zero below the diagonal
+        if (P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = ti[2] - ti[1]; P.prof[doc * 40 + 30] = tp[6] - ti[2]; P.prof[doc * 40 + 31] = ti[0] - tp[5]; }
+        // nu = R R^T = X^T X on the matrix cores, accumulated straight into the workgroup's running sum
+        // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq] = X[s4 + fq][b*16 + fr], zero below the diagonal
         v4d nud[DUMP ? NT : 1];
         if (DUMP) {
 #pragma unroll
@@ -605,9 +647,9 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
             for (int b = 0; b < NB; ++b) {
                 const int row = b * 16 + fr;
                 double v = 0.0;
-                if (row < n && col < n) {
-                    if (col == row) v = srd[row];
-                    else if (col > row && !upper) v = M[(size_t)row * MLD + col];
+                if (row < n && col < n) {   // R[row][col] = X[col][row], X lower triangular with its diagonal in M
+                    if (upper) v = (col == row) ? srd[row] : 0.0;
+                    else if (col >= row) v = M[(size_t)col * MLD + row];
                 }
                 f[b] = v;
             }
@@ -621,7 +663,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         if (REM) {   // nu[i][R0] = R[i][R0] R[R0][R0]: R is upper triangular and R0 is its last row
             double v = 0.0;
             if (lane == R0) v = Rdiag * Rdiag;
-            else if (isn && !upper) v = M[(size_t)lane * MLD + R0] * srd[R0];
+            else if (isn && !upper) v = M[(size_t)R0 * MLD + lane] * srd[R0];   // X[R0][lane] = R[lane][R0]
             nu_rem += v;
             if (DUMP && P.nu_out && isn) {
                 P.nu_out[(size_t)doc * n * n + (size_t)lane * n + R0] = v;

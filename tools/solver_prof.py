@@ -26,6 +26,7 @@ for it in range(2):
     print("   post kernel cycles/doc: " + ", ".join(f"{pn[q]} {out[:, 32 + q].mean():.0f}" for q in range(7)) + f", total {out[:, 32:39].sum(1).mean():.0f}")
     if True:
         print("   post tile phases cycles/doc: gather %.0f sums %.0f scatter %.0f H-acc %.0f" % tuple(out[:, 24:28].mean(0)))
+    print("   post inverse phases cycles/doc: diag blocks %.0f, MFMA blocks %.0f, remainder row %.0f, pre %.0f" % tuple(out[:, 28:32].mean(0)))
     for i, nm in enumerate(names):
         c, v = out[:, 8 + i].mean(), out[:, 24 + i].mean()
         if v > 0:
