@@ -199,7 +199,8 @@ class STM:
         """stm.py:497-510 with the reference's own numpy expression (element-wise `*`)."""
         sigobj = np.linalg.cholesky(self.sigma)  # LinAlgError if Sigma is not PD
         self.sigmaentropy = np.sum(np.log(np.diag(sigobj)))
-        self.siginv = np.linalg.inv(sigobj).T * np.linalg.inv(sigobj)
+        inv = np.linalg.inv(sigobj)                 # the reference inverts twice; the two results are the same array
+        self.siginv = inv.T * inv
 
     def _estep_device(self):
         """Run the kernels on the resident state; results stay in HBM."""
