@@ -405,16 +405,16 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 }
                 const double dA = lane_bcast(tA, j);
                 if (!(dA > 0.0)) { ok = false; break; }
-                const double ljj = sqrt(dA);
-                const double rjj = 1.0 / ljj;   // LAPACK dpotf2 scales the column by the reciprocal as well
+                double ljj, rjj;                // LAPACK dpotf2 scales the column by the reciprocal as well
+                sqrt_and_rsqrt(dA, ljj, rjj);
                 const double lA = (isn && lane > j) ? tA * rjj : 0.0;             // L[lane][j]
                 tB -= lA * lane_bcast(lA, j + 1);                                 // ... - L[lane][j] L[j+1][j]
                 const double dB = lane_bcast(tB, j + 1);
                 if (lane == j) Ldiag = ljj;
                 if (isn && lane > j) M[(size_t)lane * MLD + j] = lA;
                 if (!(dB > 0.0)) { ok = false; break; }
-                const double lkk = sqrt(dB);
-                const double rkk = 1.0 / lkk;
+                double lkk, rkk;
+                sqrt_and_rsqrt(dB, lkk, rkk);
                 if (lane == j + 1) Ldiag = lkk;
                 if (isn && lane > j + 1) M[(size_t)lane * MLD + j + 1] = tB * rkk;
                 STM_POST_SYNC();

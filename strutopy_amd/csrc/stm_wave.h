@@ -84,6 +84,24 @@ __device__ __forceinline__ double wave_nanmax(double v) {
     return uni(has_nan ? __builtin_nan("") : m);
 }
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p) != 0; }
+// sqrt(d) and 1 / sqrt(d) together (d > 0): the coupled Goldschmidt iteration the compiler itself expands sqrt() into
+// carries h ~ 1 / (2 sqrt(d)) along, so the reciprocal costs one more multiplication instead of an IEEE division.
+// Both results are within ~1 ulp; arguments outside the normal range go through sqrt() and the division.
+__device__ __forceinline__ void sqrt_and_rsqrt(double d, double &s, double &r) {
+    if (!(d > 1e-280 && d < 1e280)) { s = sqrt(d); r = 1.0 / s; return; }
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    const double rr = fma(-g, g, d);
+    g = fma(rr, h, g);
+    e = fma(-h, g, 0.5);          // one more step on h alone: it is returned
+    h = fma(h, e, h);
+    s = g; r = h + h;
+}
+
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
 
 // ---- Python / numpy scalar semantics scipy's line searches rely on ----------------
