@@ -54,7 +54,8 @@ int stm_device_info(stm_handle *h, char *name_out, int name_len, int *cu_count, 
  * content covariate per document, stm.py:527-528; NULL when A == 1). */
 int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr,
                    const int32_t *indices, const double *counts, const int32_t *aspect, int32_t A);
-/* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467 */
+/* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467.  2 <= K <= 128 (K <= 64: one topic per
+ * lane and the matrix-core post kernel; 64 < K <= 128: two topics per lane), STM_ERR_INVALID beyond */
 int stm_set_topics(stm_handle *h, int32_t K);
 int stm_put_beta(stm_handle *h, const double *beta /* [A][K][V] */);
 int stm_put_eta(stm_handle *h, const double *eta /* [N][K-1] */);
