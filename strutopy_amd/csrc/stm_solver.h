@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 old_old_fval = old_fval + sqrt(dot(g, g)) / 2;
                 gnorm = maxabs(g);
                 st = S_OUTER_TOP;
-            } break;
+            } [[fallthrough]];   // states that follow each other without an evaluation share one trip through the loop
             case S_OUTER_TOP: {
                 if (!(gnorm > gtol && k < maxiter)) { st = S_FINISH; break; }
                 if (H_ident) {
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
                 st = S_W1_START;
-            } break;
+            } [[fallthrough]];
             case S_W1_START: {  // scalar_search_wolfe1 + DCSRCH START
                 double a1;
                 w1_have = false;
@@ -854,41 +854,6 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 alpha = stp; need_f = true; need_g = true; want_eval = true;
                 st = S_W1_ITER;
             } break;
-            case S_W2_START: {  // scalar_search_wolfe2 (optimize/_linesearch.py:341-474)
-                alpha0 = 0;
-                if (derphi0 != 0) alpha1 = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
-                else alpha1 = 1.0;
-                if (alpha1 < 0) alpha1 = 1.0;
-                alpha1 = py_min2(alpha1, amax);
-                st = S_W2_FIRST;
-                if (w1_have && alpha1 == w1_a1) {
-                    // phi(alpha1) was DCSRCH's first evaluation (same x_k, p_k and step): scipy evaluates it
-                    // again and gets the same number
-                    fval = w1_f1; ++nfev;
-                    break;
-                }
-                alpha = alpha1; need_f = true; need_g = false; want_eval = true;
-            } break;
-            case S_W2_FIRST: {
-                phi_a1 = fval; phi_a0 = phi0; derphi_a0 = derphi0; w2_i = 0;
-                st = S_W2_TOP;
-            } break;
-            case S_W2_TOP: {
-                if (w2_i >= 10) {  // bracketing loop exhausted: alpha returned, gradient None
-                    acc_alpha = alpha1; acc_f = phi_a1; acc_have_g = false;
-                    st = S_ACCEPT;
-                    break;
-                }
-                if (alpha1 == 0 || alpha0 > amax) { status = 2; st = S_FINISH; break; }
-                if (phi_a1 > phi0 + c1 * alpha1 * derphi0 || (phi_a1 >= phi_a0 && w2_i > 0)) {
-                    a_lo = alpha0; a_hi = alpha1; phi_lo = phi_a0; phi_hi = phi_a1; derphi_lo = derphi_a0;
-                    zi = 0; phi_rec = phi0; a_rec = 0;
-                    st = S_ZOOM_TOP;
-                    break;
-                }
-                alpha = alpha1; need_f = false; need_g = true; want_eval = true;
-                st = S_W2_GOT_G;
-            } break;
             case S_W2_GOT_G: {
                 const double derphi_a1 = dval;
                 if (fabs(derphi_a1) <= -c2 * derphi0) {
@@ -912,6 +877,41 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 ++w2_i;
                 st = S_W2_TOP;
             } break;
+            case S_W2_START: {  // scalar_search_wolfe2 (optimize/_linesearch.py:341-474)
+                alpha0 = 0;
+                if (derphi0 != 0) alpha1 = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
+                else alpha1 = 1.0;
+                if (alpha1 < 0) alpha1 = 1.0;
+                alpha1 = py_min2(alpha1, amax);
+                st = S_W2_FIRST;
+                if (!(w1_have && alpha1 == w1_a1)) {
+                    alpha = alpha1; need_f = true; need_g = false; want_eval = true;
+                    break;
+                }
+                // phi(alpha1) was DCSRCH's first evaluation (same x_k, p_k and step): scipy evaluates it
+                // again and gets the same number
+                fval = w1_f1; ++nfev;
+            } [[fallthrough]];
+            case S_W2_FIRST: {
+                phi_a1 = fval; phi_a0 = phi0; derphi_a0 = derphi0; w2_i = 0;
+                st = S_W2_TOP;
+            } [[fallthrough]];
+            case S_W2_TOP: {
+                if (w2_i >= 10) {  // bracketing loop exhausted: alpha returned, gradient None
+                    acc_alpha = alpha1; acc_f = phi_a1; acc_have_g = false;
+                    st = S_ACCEPT;
+                    break;
+                }
+                if (alpha1 == 0 || alpha0 > amax) { status = 2; st = S_FINISH; break; }
+                if (!(phi_a1 > phi0 + c1 * alpha1 * derphi0 || (phi_a1 >= phi_a0 && w2_i > 0))) {
+                    alpha = alpha1; need_f = false; need_g = true; want_eval = true;
+                    st = S_W2_GOT_G;
+                    break;
+                }
+                a_lo = alpha0; a_hi = alpha1; phi_lo = phi_a0; phi_hi = phi_a1; derphi_lo = derphi_a0;
+                zi = 0; phi_rec = phi0; a_rec = 0;
+                st = S_ZOOM_TOP;
+            } [[fallthrough]];
             case S_ZOOM_TOP: {  // _zoom (optimize/_linesearch.py:532-621)
                 // same bound as in S_W1_ITER: every later a_j lies between a_lo and a_hi, and zoom accepts
                 // only when |phi'(a_j)| <= 0.9 |phi'(0)|; if that is out of reach the remaining iterations
@@ -944,7 +944,9 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 const double phi_aj = fval;
                 if (phi_aj > phi0 + c1 * a_j * derphi0 || phi_aj >= phi_lo) {
                     phi_rec = phi_hi; a_rec = a_hi; a_hi = a_j; phi_hi = phi_aj;
-                    st = S_ZOOM_NEXT;
+                    ++zi;   // S_ZOOM_NEXT, inlined
+                    if (zi > 10) { status = 2; st = S_FINISH; break; }
+                    st = S_ZOOM_TOP;
                     break;
                 }
                 alpha = a_j; need_f = false; need_g = true; want_eval = true;
@@ -964,7 +966,9 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     phi_rec = phi_lo; a_rec = a_lo;
                 }
                 a_lo = a_j; phi_lo = phi_aj; derphi_lo = derphi_aj;
-                st = S_ZOOM_NEXT;
+                ++zi;   // S_ZOOM_NEXT, inlined
+                if (zi > 10) { status = 2; st = S_FINISH; break; }
+                st = S_ZOOM_TOP;
             } break;
             case S_ZOOM_NEXT: {
                 ++zi;
