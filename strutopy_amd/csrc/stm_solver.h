@@ -232,11 +232,24 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         const int64_t ticket = P.first + blockIdx.x;
         if (ticket >= P.N) return;
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
+        const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
         const int64_t p0 = P.indptr[doc];
         const int Nd = (int)(P.indptr[doc + 1] - p0);
         const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
         const int asp = P.aspect ? P.aspect[doc] : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
+
+        // lane vectors first: their loads fly while the beta rows are gathered
+        double x[VPL], g[VPL], p[VPL], xt[VPL], gv[VPL], mu[VPL], sd[VPL], g0[VPL];
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) {
+            const int i = lane + WAVE * r;
+            const bool act = i < n;
+            x[r] = act ? P.eta[doc * n + i] : 0.0;
+            mu[r] = act ? P.mu[doc * n + i] : 0.0;
+            sd[r] = act ? S[(size_t)i * n + i] : 0.0;
+            g[r] = 0.0; p[r] = 0.0; xt[r] = 0.0; gv[r] = 0.0; g0[r] = 0.0;
+        }
 
         // ---- gather beta_d (stm.py:614-617), lane = word; assert beta >= 0 (stm.py:534)
         double csum = 0.0;
@@ -244,24 +257,77 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         double breg[KR];   // beta_d[:, word] of word `wv*64 + lane` (KREG > 0)
         double c0 = 0.0, w0 = 0.0;
         const int wreg = wv * WAVE + lane;  // this lane's register-resident word
+        constexpr bool COOP = !GLOBAL_SLAB && VPL == 1;   // LDS slab: its rows are gathered lane = topic, one coalesced run per word
+        constexpr int SB = 16;                             // slab rows fetched together with the register-resident rows
+        const bool act = KREG > 0 && wreg < Nd;
+        // every index first (one memory round trip), then every row that fits in flight (a second one)
+        const int idx_reg = act ? P.indices[p0 + wreg] : 0;
+        const int idx_slab = (COOP && lane < NdL) ? P.indices[p0 + VREG + lane] : 0;
+        if (act) c0 = P.counts[p0 + wreg];
         if (KREG > 0) {
-            const bool act = wreg < Nd;
-            const int idx = act ? P.indices[p0 + wreg] : 0;
-            const double *row = bT + (size_t)idx * K;
+            const double *row = bT + (size_t)idx_reg * K;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) breg[k] = (act && k < K) ? row[k] : 0.0;
+        }
+        double bv0[COOP ? SB : 1];
+        if (COOP) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = __builtin_amdgcn_readlane(idx_slab, u);
+                bv0[u] = (lane < K && u < NdL) ? bT[(size_t)idx * K + lane] : 0.0;
+            }
+        }
+        if (KREG > 0) {
             double colsum = 0.0;
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
-                const double b = (act && k < K) ? row[k] : 0.0;
-                bad |= !(b >= 0.0);
-                breg[k] = b;
-                colsum += b;
+                bad |= !(breg[k] >= 0.0);
+                colsum += breg[k];
             }
             if (act) {
-                c0 = P.counts[p0 + wreg];
                 w0 = c0 / colsum;
                 csum += c0;
             }
         }
+        if (COOP) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+                if (u < NdL) {   // uniform
+                    bad |= !(bv0[u] >= 0.0);
+                    if (lane < K) slab[(size_t)u * KP + lane] = bv0[u];
+                }
+            // the rest of the slab, eight rows in flight
+            for (int v0 = 0; v0 < NdL; v0 += WAVE) {
+                const int cnt = NdL - v0 < WAVE ? NdL - v0 : WAVE;
+                const int my_idx = v0 == 0 ? idx_slab : (lane < cnt ? P.indices[p0 + VREG + v0 + lane] : 0);
+                for (int j0 = (v0 == 0 ? SB : 0); j0 < cnt; j0 += 8) {
+                    double bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = __builtin_amdgcn_readlane(my_idx, (j0 + u) & (WAVE - 1));
+                        bv[u] = (lane < K && j0 + u < cnt) ? bT[(size_t)idx * K + lane] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < cnt) {   // uniform
+                            bad |= !(bv[u] >= 0.0);
+                            if (lane < K) slab[(size_t)(v0 + j0 + u) * KP + lane] = bv[u];
+                        }
+                }
+            }
+            STM_WAVE_SYNC();
+            // lane = word again for the column sums (same order of additions as the per-lane loop below)
+            for (int vv = lane; vv < NdL; vv += WAVE) {
+                const double c = P.counts[p0 + VREG + vv];
+                double *dst = slab + (size_t)vv * KP;
+                double colsum = 0.0;
+                for (int k = 0; k < K; ++k) colsum += dst[k];
+                for (int k = K; k < KP; ++k) dst[k] = 0.0;
+                crow[vv] = c;
+                wrow[vv] = c / colsum;
+                csum += c;
+            }
+        } else
         for (int vv = lane; vv < NdL; vv += WAVE) {
             const int idx = P.indices[p0 + VREG + vv];
             const double c = P.counts[p0 + VREG + vv];
@@ -279,6 +345,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             wrow[vv] = c / colsum;
             csum += c;
         }
+        const long long t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
         // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
         if (wv == 0)
             for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
@@ -298,17 +365,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         }
         const ud Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
 
-        // ---- lane vectors
-        double x[VPL], g[VPL], p[VPL], xt[VPL], gv[VPL], mu[VPL], sd[VPL], g0[VPL];
-#pragma unroll
-        for (int r = 0; r < VPL; ++r) {
-            const int i = lane + WAVE * r;
-            const bool act = i < n;
-            x[r] = act ? P.eta[doc * n + i] : 0.0;
-            mu[r] = act ? P.mu[doc * n + i] : 0.0;
-            sd[r] = act ? S[(size_t)i * n + i] : 0.0;
-            g[r] = 0.0; p[r] = 0.0; xt[r] = 0.0; gv[r] = 0.0; g0[r] = 0.0;
-        }
+        const long long t_g2 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
         // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
         auto g0_slab = [&](int k) __attribute__((always_inline)) -> double {
             double t = 0.0;
@@ -320,7 +377,33 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             for (int r = 0; r < VPL; ++r)
                 if (k == lane + WAVE * r) g0[r] = t;
         };
-        if (KREG > 0) {
+        if (KREG > 0 && VPL == 1) {
+            // wave_sum()'s additions in wave_sum()'s order, but the four row totals of every topic are combined for all
+            // topics at once: after the intra-row steps lane (row r, position c) keeps the row-r total of topic 16 q + c
+            // in acc[q]; two cross-row exchanges per q finish the sums, and lane k picks topic k.
+            double accq[4] = {0.0, 0.0, 0.0, 0.0};
+            const int c16 = lane & 15;
+#pragma unroll
+            for (int k = 0; k < KR; ++k)
+                if (k < n) {
+                    double v = breg[k] * w0 + g0_slab(k);
+                    v += dpp_move<DPP_XOR1>(v);
+                    v += dpp_move<DPP_XOR2>(v);
+                    v += dpp_move<DPP_HALF_MIRROR>(v);
+                    v += dpp_move<DPP_MIRROR>(v);
+                    if ((k & 15) == c16) accq[k >> 4] = v;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 16 < n) {
+                    double a = accq[q];
+                    a += __shfl_xor(a, 16);       // rows (0,1) and (2,3): lane_bcast(v, 0) + lane_bcast(v, 16) ...
+                    a += __shfl_xor(a, 32);       // ... + (lane_bcast(v, 32) + lane_bcast(v, 48))
+                    accq[q] = a;
+                }
+            const int q = lane >> 4;
+            g0[0] = (lane < n) ? (q == 0 ? accq[0] : q == 1 ? accq[1] : q == 2 ? accq[2] : accq[3]) : 0.0;
+        } else if (KREG > 0) {
 #pragma unroll
             for (int k = 0; k < KR; ++k)
                 if (k < n) g0_put(k, wave_sum(breg[k] * w0 + g0_slab(k)));
@@ -328,7 +411,9 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             for (int k = 0; k < n; ++k) g0_put(k, wave_sum(g0_slab(k)));
         }
 
-        long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0, t_init = 0, t_eval = 0, t_sm = 0, t_upd = 0;
+        const long long t_g3 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+        if (P.prof && lane == 0 && wv == 0) { P.prof[doc * 40 + 4] = t_g1 - t_begin; P.prof[doc * 40 + 5] = t_g2 - t_g1; P.prof[doc * 40 + 6] = t_g3 - t_g2; }
+        long long t_init = 0, t_eval = 0, t_sm = 0, t_upd = 0;
         int nfev = 0, njev = 0;
         double *svx = (NW == 2 && wv == 1) ? svb : sv;  // this wave's private broadcast vector
 
