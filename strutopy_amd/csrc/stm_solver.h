@@ -231,8 +231,8 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
     {
         const int64_t ticket = P.first + blockIdx.x;
         if (ticket >= P.N) return;
-        const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
+        const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
         const int Nd = (int)(P.indptr[doc + 1] - p0);
         const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
@@ -258,11 +258,12 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         double c0 = 0.0, w0 = 0.0;
         const int wreg = wv * WAVE + lane;  // this lane's register-resident word
         constexpr bool COOP = !GLOBAL_SLAB && VPL == 1;   // LDS slab: its rows are gathered lane = topic, one coalesced run per word
-        constexpr int SB = 16;                             // slab rows fetched together with the register-resident rows
+        constexpr int SB = 24;                             // slab rows fetched together with the register-resident rows (all of them at ~150 words)
         const bool act = KREG > 0 && wreg < Nd;
         // every index first (one memory round trip), then every row that fits in flight (a second one)
         const int idx_reg = act ? P.indices[p0 + wreg] : 0;
         const int idx_slab = (COOP && lane < NdL) ? P.indices[p0 + VREG + lane] : 0;
+        const double cnt_slab = (COOP && lane < NdL) ? P.counts[p0 + VREG + lane] : 0.0;
         if (act) c0 = P.counts[p0 + wreg];
         if (KREG > 0) {
             const double *row = bT + (size_t)idx_reg * K;
@@ -318,11 +319,19 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             STM_WAVE_SYNC();
             // lane = word again for the column sums (same order of additions as the per-lane loop below)
             for (int vv = lane; vv < NdL; vv += WAVE) {
-                const double c = P.counts[p0 + VREG + vv];
+                const double c = vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
                 double *dst = slab + (size_t)vv * KP;
                 double colsum = 0.0;
-                for (int k = 0; k < K; ++k) colsum += dst[k];
-                for (int k = K; k < KP; ++k) dst[k] = 0.0;
+                int k = 0;
+                for (; k + 7 < K; k += 8) {   // eight LDS reads in flight, the additions stay in order
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = dst[k + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) colsum += t[u];
+                }
+                for (; k < K; ++k) colsum += dst[k];
+                for (k = K; k < KP; ++k) dst[k] = 0.0;
                 crow[vv] = c;
                 wrow[vv] = c / colsum;
                 csum += c;
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             csum += c;
         }
         const long long t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+        if (P.prof && NW == 2 && wv == 1 && lane == 0) P.prof[doc * 40 + 7] = t_g1 - t_begin;   // wave 1: register rows + slab
         // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
         if (wv == 0)
             for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
