@@ -22,6 +22,7 @@
 // estimate lives in a private global slab (n x n, touched only nit times).  Lane i holds
 // component i of every length-(K-1) vector; all line-search scalars are wave-uniform.
 #pragma once
+#include <type_traits>
 #include "stm_wave.h"
 
 namespace stm {
@@ -393,19 +394,30 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             // in acc[q]; two cross-row exchanges per q finish the sums, and lane k picks topic k.
             double accq[4] = {0.0, 0.0, 0.0, 0.0};
             const int c16 = lane & 15;
+            // straight-line code for all KREG topics (rows K.. of the registers are zeros, topic K-1 is computed and dropped),
+            // so that the KREG reduction chains interleave; three forms of the slab term: none (this wave owns no slab
+            // words), one word per lane (at most 64 slab words), the general strided loop
+            const double wl = (NdL > 0 && NdL <= WAVE && lane < NdL) ? wrow[lane] : 0.0;
+            const double *srow = slab + (size_t)((NdL <= WAVE && lane < NdL) ? lane : 0) * KP;
+            auto chains = [&](auto mode) __attribute__((always_inline)) {
 #pragma unroll
-            for (int k = 0; k < KR; ++k)
-                if (k < n) {
-                    double v = breg[k] * w0 + g0_slab(k);
+                for (int k = 0; k < KR; ++k) {
+                    double v = breg[k] * w0;
+                    if (decltype(mode)::value == 1) v = v + ((lane < NdL) ? srow[k] * wl : 0.0);
+                    if (decltype(mode)::value == 2) v = v + g0_slab(k);
                     v += dpp_move<DPP_XOR1>(v);
                     v += dpp_move<DPP_XOR2>(v);
                     v += dpp_move<DPP_HALF_MIRROR>(v);
                     v += dpp_move<DPP_MIRROR>(v);
                     if ((k & 15) == c16) accq[k >> 4] = v;
                 }
+            };
+            if (NdL == 0) chains(std::integral_constant<int, 0>());
+            else if (NdL <= WAVE) chains(std::integral_constant<int, 1>());
+            else chains(std::integral_constant<int, 2>());
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (q * 16 < n) {
+                if (q * 16 < KR) {
                     double a = accq[q];
                     a += __shfl_xor(a, 16);       // rows (0,1) and (2,3): lane_bcast(v, 0) + lane_bcast(v, 16) ...
                     a += __shfl_xor(a, 32);       // ... + (lane_bcast(v, 32) + lane_bcast(v, 48))
