@@ -358,7 +358,7 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = use_device(h)) return rc;
     h->K = K; h->n = K - 1;
     const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
-    if (int rc = dalloc(&h->d_betaT, KV)) return rc;
+    if (int rc = dalloc(&h->d_betaT, KV + 64)) return rc;   // + 64: the solver reads KREG <= 64 doubles from a row start, masked beyond K
     // one packed buffer [ scalars(8) | sigma_ss | extra | beta_ss ] so a single all-reduce covers it
     h->pack_len = 8 + n * n + STM_EXTRA_MAX + KV;
     if (int rc = dalloc(&h->d_pack, h->pack_len)) return rc;

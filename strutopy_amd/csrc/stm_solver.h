@@ -233,11 +233,11 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         const int64_t ticket = P.first + blockIdx.x;
         if (ticket >= P.N) return;
         const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
-        const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
-        const int64_t p0 = P.indptr[doc];
-        const int Nd = (int)(P.indptr[doc + 1] - p0);
+        const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
+        const int64_t p0 = scalar_load(P.indptr + doc);
+        const int Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
         const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
-        const int asp = P.aspect ? P.aspect[doc] : 0;
+        const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
 
         // lane vectors first: their loads fly while the beta rows are gathered
@@ -267,9 +267,24 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         const double cnt_slab = (COOP && lane < NdL) ? P.counts[p0 + VREG + lane] : 0.0;
         if (act) c0 = P.counts[p0 + wreg];
         if (KREG > 0) {
+            // unconditional loads of KREG doubles from the row start (the buffer is padded; rows are 16-byte aligned for even K),
+            // zeros beyond K by selection: no branch per topic
             const double *row = bT + (size_t)idx_reg * K;
+            if ((K & 1) == 0) {
+                const double2 *row2 = reinterpret_cast<const double2 *>(row);
 #pragma unroll
-            for (int k = 0; k < KR; ++k) breg[k] = (act && k < K) ? row[k] : 0.0;
+                for (int k = 0; k < KR; k += 2) {
+                    const double2 t = row2[k >> 1];
+                    breg[k] = (act && k < K) ? t.x : 0.0;
+                    breg[k + 1] = (act && k + 1 < K) ? t.y : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KR; ++k) {
+                    const double t = row[k];
+                    breg[k] = (act && k < K) ? t : 0.0;
+                }
+            }
         }
         double bv0[COOP ? SB : 1];
         if (COOP) {

@@ -37,6 +37,13 @@ struct ud {
     }
 };
 
+// Uniform read of kernel-lifetime-constant global data through the scalar cache (s_load): the compiler only does this on
+// its own when it can prove that nobody writes the buffer, which it cannot for plain pointers in a parameter struct.
+template <typename T>
+__device__ __forceinline__ T scalar_load(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 // value held by lane `src` (uniform src) -> uniform
 __device__ __forceinline__ double lane_bcast(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
