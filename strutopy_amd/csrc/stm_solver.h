@@ -279,20 +279,21 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                     breg[k + 1] = (act && k + 1 < K) ? t.y : 0.0;
                 }
             } else {
+                double tmp[KR];
 #pragma unroll
-                for (int k = 0; k < KR; ++k) {
-                    const double t = row[k];
-                    breg[k] = (act && k < K) ? t : 0.0;
-                }
+                for (int k = 0; k < KR; ++k) tmp[k] = row[k];
+#pragma unroll
+                for (int k = 0; k < KR; ++k) breg[k] = (act && k < K) ? tmp[k] : 0.0;
             }
         }
         double bv0[COOP ? SB : 1];
-        if (COOP) {
+        if (COOP && NdL > 0) {   // one block of SB loads (unused slots fetch word 0's row), issued behind the register rows
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
                 const int idx = __builtin_amdgcn_readlane(idx_slab, u);
-                bv0[u] = (lane < K && u < NdL) ? bT[(size_t)idx * K + lane] : 0.0;
+                bv0[u] = bT[(size_t)idx * K + (lane < K ? lane : 0)];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (KREG > 0) {
             double colsum = 0.0;
