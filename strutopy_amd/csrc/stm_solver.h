@@ -333,26 +333,8 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                         }
                 }
             }
-            STM_WAVE_SYNC();
-            // lane = word again for the column sums (same order of additions as the per-lane loop below)
-            for (int vv = lane; vv < NdL; vv += WAVE) {
-                const double c = vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
-                double *dst = slab + (size_t)vv * KP;
-                double colsum = 0.0;
-                int k = 0;
-                for (; k + 7 < K; k += 8) {   // eight LDS reads in flight, the additions stay in order
-                    double t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = dst[k + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) colsum += t[u];
-                }
-                for (; k < K; ++k) colsum += dst[k];
-                for (k = K; k < KP; ++k) dst[k] = 0.0;
-                crow[vv] = c;
-                wrow[vv] = c / colsum;
-                csum += c;
-            }
+            // the word counts now (the other wave waits for their sum); the column sums of the slab rows after the exchange
+            for (int vv = lane; vv < NdL; vv += WAVE) csum += vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
         } else
         for (int vv = lane; vv < NdL; vv += WAVE) {
             const int idx = P.indices[p0 + VREG + vv];
@@ -391,6 +373,29 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
             return;
         }
         const ud Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
+        if (COOP && NdL > 0) {
+            // lane = word again for the column sums of the slab rows (same order of additions as the per-lane gather loop);
+            // only this wave reads crow / wrow before the next hand-off
+            STM_WAVE_SYNC();
+            for (int vv = lane; vv < NdL; vv += WAVE) {
+                const double c = vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
+                double *dst = slab + (size_t)vv * KP;
+                double colsum = 0.0;
+                int k = 0;
+                for (; k + 7 < K; k += 8) {   // eight LDS reads in flight, the additions stay in order
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = dst[k + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) colsum += t[u];
+                }
+                for (; k < K; ++k) colsum += dst[k];
+                for (k = K; k < KP; ++k) dst[k] = 0.0;
+                crow[vv] = c;
+                wrow[vv] = c / colsum;
+            }
+            STM_WAVE_SYNC();
+        }
 
         const long long t_g2 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
         // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
