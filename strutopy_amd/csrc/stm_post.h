@@ -121,10 +121,11 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
         const int64_t ticket = P.first + tk;
-        const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
-        const int64_t p0 = P.indptr[doc];
-        const int Nd = (int)(P.indptr[doc + 1] - p0);
-        const int asp = P.aspect ? P.aspect[doc] : 0;
+        // the document header through the scalar cache (uniform, constant for the kernel's lifetime)
+        const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
+        const int64_t p0 = scalar_load(P.indptr + doc);
+        const int Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
+        const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
         double *bssT = P.beta_ssT + (size_t)asp * (size_t)P.V * K;
         const bool dump_phi = P.phi_out && doc == P.phi_doc;
