@@ -174,6 +174,49 @@ def test_k100_two_topics_per_lane(oracle, monkeypatch):
     assert np.allclose(out[0][3], out[1][3], rtol=1e-6, atol=1e-8)
 
 
+def test_content_levels_at_k50(oracle):
+    """Per-level beta (content covariate, A = 3 levels) at the headline K = 50: the aspect selects the beta the rows are
+    gathered from and the beta_ss slice phi is added to (stm.py:527-528, 584-588), through the 3 x 3-block + remainder-row
+    post kernel and the two-wave solver, documents on both sides of the 128-word register limit."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(350)
+    K, V, N, A = 50, 1500, 90, 3
+    lens = rng.integers(1, 230, size=N)
+    docs = [np.sort(rng.choice(V, int(L), replace=False)) for L in lens]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 4, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(A, K, V)); beta /= beta.sum(axis=2)[:, :, None]
+    aspect = rng.integers(0, A, size=N).astype(np.int32)
+    n = K - 1
+    mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
+    siginv, sigent = oracle.preamble(np.eye(n) * 20.0)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    _check(estep_host(*args, aspect=aspect), oracle.estep(*args, aspect=aspect, nthreads=0), "A=3, K=50")
+
+
+@pytest.mark.parametrize("mode", [3, 1, 2])
+def test_solver_variants_agree_with_the_oracle(oracle, monkeypatch, mode):
+    """STM_SOLVER_MODE picks the other data paths of the solver (3: one wave per document, beta_d in registers + LDS; 1: LDS
+    slab only; 2: the global slab long documents fall back to): same scipy trajectory, same results."""
+    from strutopy_amd.engine import estep_host
+    monkeypatch.setenv("STM_SOLVER_MODE", str(mode))
+    g = load_golden("c1_k10")
+    args = (g["indptr"], g["indices"], g["counts"], g["beta0"], g["it0_mu_in"], g["it0_eta_in"], g["it0_siginv"],
+            float(g["it0_sigmaentropy"]))
+    d = estep_host(*args)
+    assert np.array_equal(d["status"], g["it0_status"]) and np.array_equal(d["nit"], g["it0_nit"])
+    assert np.max(np.abs(d["eta"] - g["it0_eta"])) <= 1e-7
+    assert abs(d["bound_doc"].sum() - float(g["it0_bound"])) <= 1e-9 * abs(float(g["it0_bound"]))
+    g = load_golden("k50_v10k")
+    beta = reference_beta0(int(g["K"]), int(g["V"]))
+    args = (g["indptr"], g["indices"], g["counts"], beta, g["it0_mu_in"], g["it0_eta_in"], g["it0_siginv"],
+            float(g["it0_sigmaentropy"]))
+    d = estep_host(*args)
+    assert np.array_equal(d["status"], g["it0_status"]) and np.array_equal(d["nit"], g["it0_nit"])
+    assert np.max(np.abs(d["eta"] - g["it0_eta"])) <= 1e-7
+
+
 def test_documents_longer_than_the_lds(oracle):
     """A document whose K x Nd block cannot live in the 160 KB LDS takes the global-slab solver variant;
     shorter ones in the same corpus stay on chip."""
