@@ -565,13 +565,18 @@ static int bfgs_minimize(doc_t *d, double *x, int *nit_out, double *fun_out) {
 /* ------------------------------------------------------------------ */
 /* Hessian, PD fix, Cholesky, nu, bound, phi                           */
 /* ------------------------------------------------------------------ */
+#define STM_PIVOT_TOL (32.0 * 2.220446049250313e-16)
 /* np.linalg.cholesky (lower).  Returns 0 on success, 1 when not PD. L's upper part is zeroed. */
 static int chol_lower(int n, const double *A, double *L) {
     for (size_t i = 0; i < (size_t)n * n; ++i) L[i] = 0.0;
     for (int j = 0; j < n; ++j) {
         double dsum = A[(size_t)j * n + j];
         for (int l = 0; l < j; ++l) dsum -= L[(size_t)j * n + l] * L[(size_t)j * n + l];
-        if (!(dsum > 0.0)) return 1;
+        /* A pivot that is nothing but the rounding left over from cancelling A[j][j] counts as failed.  make_pd can
+         * produce an EXACTLY singular matrix (n = 2: [[|o|, o], [o, |o|]], every time both diagonals are raised), and
+         * there the sign of the pivot -- like the sign of the smallest eigenvalue the reference tests -- is decided
+         * by the last bit of the input; "failed" leads to the + 1e-5 branch instead of a factor with a 1e-8 pivot. */
+        if (!(dsum > STM_PIVOT_TOL * A[(size_t)j * n + j])) return 1;
         double ljj = sqrt(dsum);
         L[(size_t)j * n + j] = ljj;
         for (int i = j + 1; i < n; ++i) {

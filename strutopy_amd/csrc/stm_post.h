@@ -58,6 +58,10 @@ struct PostParams {
     long long *prof;       // optional [N][40] (shared with the solver's): [32..39] post-kernel phase cycles
 };
 
+// A Cholesky pivot that is only the rounding left over from cancelling the diagonal entry counts as failed (as in the
+// oracle): make_pd can leave an exactly singular matrix (n = 2: always when both diagonals are raised), and the sign of such a
+// pivot -- like the sign of the smallest eigenvalue the reference tests, stm.py:1017 -- hangs on the last bit of the input.
+constexpr double PIVOT_TOL = 32.0 * 2.220446049250313e-16;
 constexpr int PT = 64;    // topics padded to 64 (K <= 64 in this kernel)
 constexpr int TW = 16;    // words per tile
 constexpr int TLD = 18;   // leading dimension of T: MFMA fragment reads are conflict-free
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     if (lane > j) tB = ((lane == j + 1) ? diagA : rk[lane]) - (b0 + b1);
                 }
                 const double dA = lane_bcast(tA, j);
-                if (!(dA > 0.0)) { ok = false; break; }
+                if (!(dA > PIVOT_TOL * lane_bcast(diagA, j))) { ok = false; break; }   // see PIVOT_TOL
                 double ljj, rjj;                // LAPACK dpotf2 scales the column by the reciprocal as well
                 sqrt_and_rsqrt(dA, ljj, rjj);
                 const double lA = (isn && lane > j) ? tA * rjj : 0.0;             // L[lane][j]
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 const double dB = lane_bcast(tB, j + 1);
                 if (lane == j) Ldiag = ljj;
                 if (isn && lane > j) M[(size_t)lane * MLD + j] = lA;
-                if (!(dB > 0.0)) { ok = false; break; }
+                if (!(dB > PIVOT_TOL * lane_bcast(diagA, j + 1))) { ok = false; break; }
                 double lkk, rkk;
                 sqrt_and_rsqrt(dB, lkk, rkk);
                 if (lane == j + 1) Ldiag = lkk;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     t = diagA - a0;
                 }
                 const double d = lane_bcast(t, j);
-                if (!(d > 0.0)) ok = false;
+                if (!(d > PIVOT_TOL * lane_bcast(diagA, j))) ok = false;
                 else if (lane == j) Ldiag = sqrt(d);
             }
             STM_POST_SYNC();

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                     if (k1 < n && k1 >= j) t[1] = ((k1 == j) ? diagA[1] : rj[k1]) - ((b[0] + b[1]) + (b[2] + b[3]));
                 }
                 const double d = lane_bcast((j >> 6) ? t[1] : t[0], j & 63);
-                if (!(d > 0.0)) { ok = false; break; }
+                if (!(d > PIVOT_TOL * lane_bcast((j >> 6) ? diagA[1] : diagA[0], j & 63))) { ok = false; break; }
                 const double ljj = sqrt(d), rjj = 1.0 / ljj;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {

@@ -55,7 +55,8 @@ struct SolverParams {
     const int32_t *order;   // optional processing order (nullable)
     int32_t *status, *nit, *nfev, *njev;
     int32_t *err_flag;
-    int debug_flags;        // bit0: skip the BFGS loop (bring-up aid)
+    int debug_flags;        // bit0: skip the BFGS loop (bring-up aid); bit1: no line-search cuts, bit2: no reuse of DCSRCH's first
+                            // evaluation by wolfe2 (every evaluation scipy makes is made: A/B check of the shortcuts)
     long long *prof;        // optional [N][40] shader-clock totals per document: [0] init, [1] evaluations, [2] state machine,
                             // [3] BFGS update, [8+st] cycles in state st, [24+st] visits of state st
 };
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
         };
 
         if (P.debug_flags & 1) st = S_FINISH;
+        const bool cuts = !(P.debug_flags & 2), reuse = !(P.debug_flags & 4);
         long guard = 0;
         if (P.prof) t_init = (long long)__builtin_readcyclecounter() - t_begin;
         while (st != S_FINISH) {
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 // remains is ~60 evaluations inside rounding noise that can only end in a WARNING or
                 // the 100-call cap, i.e. alpha = None and the hand-over to wolfe2, whose start does
                 // not depend on DCSRCH's final state.
-                if (brackt) {
+                if (brackt && cuts) {
                     const double smax = py_max2(stx, sty), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
                     if (smax * Ls <= 0.05 * -derphi0) { st = S_W2_START; break; }
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 if (alpha1 < 0) alpha1 = 1.0;
                 alpha1 = py_min2(alpha1, amax);
                 st = S_W2_FIRST;
-                if (!(w1_have && alpha1 == w1_a1)) {
+                if (!(reuse && w1_have && alpha1 == w1_a1)) {
                     alpha = alpha1; need_f = true; need_g = false; want_eval = true;
                     break;
                 }
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void s
                 // same bound as in S_W1_ITER: every later a_j lies between a_lo and a_hi, and zoom accepts
                 // only when |phi'(a_j)| <= 0.9 |phi'(0)|; if that is out of reach the remaining iterations
                 // can only exhaust maxiter = 10 -> _LineSearchError -> status 2 with x unchanged
-                if (a_lo >= 0 && a_hi >= 0) {
+                if (cuts && a_lo >= 0 && a_hi >= 0) {
                     const double smax = py_max2(a_lo, a_hi), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
                     if (smax * Ls <= 0.05 * -derphi0) { status = 2; st = S_FINISH; break; }
