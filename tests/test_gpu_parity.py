@@ -217,6 +217,21 @@ def test_solver_variants_agree_with_the_oracle(oracle, monkeypatch, mode):
     assert np.max(np.abs(d["eta"] - g["it0_eta"])) <= 1e-7
 
 
+def test_exactly_singular_hessian_after_make_pd(oracle):
+    """K = 3: make_pd turns the 2 x 2 Hessian of some documents into [[|o|, o], [o, |o|]], exactly singular; the sign of the second
+    pivot (like the sign of the smallest eigenvalue the reference tests, stm.py:1017) is rounding noise there.  Oracle and kernels
+    count a pivot within 32 ulp of the cancelled diagonal as failed, so both take the + 1e-5 branch and nu
+    stays finite.  Inputs: a case found by tools/fuzz_parity.py (58 documents, three beta levels, counts up to 1000)."""
+    from strutopy_amd.engine import estep_host
+    g = load_golden("k3_singular_inputs")
+    args = (g["indptr"], g["indices"], g["counts"], g["beta"], g["mu"], g["eta"], g["siginv"], float(g["sigent"]))
+    o = oracle.estep(*args, aspect=g["aspect"], nthreads=0)
+    d = estep_host(*args, aspect=g["aspect"])
+    assert np.bincount(o["pd_path"], minlength=3)[2] >= 2          # the singular documents are in there
+    _check(d, o, "K=3 singular")
+    assert np.isfinite(d["sigma_ss"]).all() and np.max(np.abs(d["sigma_ss"])) < 1e7
+
+
 def test_documents_longer_than_the_lds(oracle):
     """A document whose K x Nd block cannot live in the 160 KB LDS takes the global-slab solver variant;
     shorter ones in the same corpus stay on chip."""
