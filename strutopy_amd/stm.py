@@ -253,12 +253,15 @@ class STM:
         logger.info(f"Completed M-Step in {np.round(time.time() - start_time, 3)} seconds. \n")
 
     def _regress(self, prev_cov, eta, intercept=True):
+        # sklearn flattens coef_ for a single target (K = 2), which sends the reference's mu = X @ coef_.T (stm.py:704) to
+        # shape (N,) and its Sigma to N x N; here the coefficients keep their (K-1) x p shape
+        shape = (eta.shape[1], prev_cov.shape[1])
         if self.mode == "lasso":
             import sklearn.linear_model
-            return sklearn.linear_model.Lasso(alpha=1, fit_intercept=intercept).fit(prev_cov, eta).coef_
+            return np.reshape(sklearn.linear_model.Lasso(alpha=1, fit_intercept=intercept).fit(prev_cov, eta).coef_, shape)
         if self.mode == "ridge":
             import sklearn.linear_model
-            return sklearn.linear_model.Ridge(alpha=0.1, fit_intercept=intercept).fit(prev_cov, eta).coef_
+            return np.reshape(sklearn.linear_model.Ridge(alpha=0.1, fit_intercept=intercept).fit(prev_cov, eta).coef_, shape)
         if self.mode != "ols":
             print("Need to specify the estimation mode of prevalence covariate coefficients. Uses default 'ols'.")
         # sklearn LinearRegression(fit_intercept=True): centre, then minimum-norm least squares
