@@ -17,6 +17,9 @@ for flags in ("0", "6"):
     d = estep_host(*args, aspect=asp)
     bad = np.nonzero((d["nit"] != o["nit"]) | (d["status"] != o["status"]) | (d["pd_path"] != o["pd_path"]))[0]
     print(f"STM_DEBUG_FLAGS={flags}: {len(bad)} documents differ; nfev mean gpu {d['nfev'].mean():.1f} oracle {o['nfev'].mean():.1f}")
+    de = np.max(np.abs(d["eta"] - o["eta"]), axis=1)
+    for i in np.argsort(-de)[:3]:
+        print(f"   largest |eta diff|: doc {i} {de[i]:.2e}  words {int(g['indptr'][i + 1] - g['indptr'][i])}  N_d {g['counts'][g['indptr'][i]:g['indptr'][i + 1]].sum():.0f}  nit {d['nit'][i]} / {o['nit'][i]}  nfev {d['nfev'][i]} / {o['nfev'][i]}")
     for i in bad[:10]:
         print(f"   doc {i}: nit {d['nit'][i]} / {o['nit'][i]}  status {d['status'][i]} / {o['status'][i]}  nfev {d['nfev'][i]} / {o['nfev'][i]}  "
               f"pd {d['pd_path'][i]} / {o['pd_path'][i]}  |eta diff| {np.max(np.abs(d['eta'][i] - o['eta'][i])):.2e}  (gpu / oracle)")

@@ -3,7 +3,7 @@
 cases of tests/test_gpu_parity.py).  Random K, V, document lengths, counts, eta / mu scales, diagonal or dense siginv, one or
 several beta levels; scipy status / nit / PD path must agree exactly, values to the tolerances of DESIGN.md section 7.
 
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tools/fuzz_parity.py [n_cases] [seed] [long]      # long: vocabularies up to 9000 and one document using most of it
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,13 +15,16 @@ from strutopy_amd.engine import estep_host
 stm_oracle.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+LONG = len(sys.argv) > 3
 bad = 0
 for case in range(n_cases):
     K = int(rng.choice([2, 3, 5, 10, 16, 17, 18, 33, 34, 49, 50, 51, 64, 65, 80, 100, 128]))
-    V = int(rng.integers(max(K, 40), 4000))
+    V = int(rng.integers(3000, 9000)) if LONG else int(rng.integers(max(K, 40), 4000))
     N = int(rng.integers(1, 80))
     maxlen = int(rng.choice([3, 20, 70, 140, 200, 400, min(V, 1500)]))
     lens = rng.integers(1, min(V, maxlen) + 1, size=N)
+    if LONG:
+        lens[int(rng.integers(0, N))] = int(rng.integers(V // 2, V))   # beyond the LDS for most K: the global-slab solver variant
     docs = [np.sort(rng.choice(V, int(L), replace=False)) for L in lens]
     indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     indices = np.concatenate(docs).astype(np.int32)
