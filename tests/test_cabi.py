@@ -87,3 +87,23 @@ def test_null_and_order_checks_do_not_need_a_device():
     assert L.stm_create(None, 0) == _lib.STM_ERR_INVALID
     assert b"" != L.stm_last_error()
     L.stm_destroy(None)
+
+
+def test_integration_stub_matches_the_binding():
+    """The ctypes stub INTEGRATION.md hands to a reference maintainer declares struct stm_estep_args exactly like the package's own
+    binding (field names, order, C types), and only calls entry points the header declares."""
+    import re
+    import ctypes as C
+    from strutopy_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("class _Args(C.Structure)"):text.index("_lib.stm_estep_host.argtypes")]
+    doc_fields = re.findall(r'\("(\w+)",\s*([\w.]+)\)', block)
+    types = {"C.c_int64": C.c_int64, "C.c_int32": C.c_int32, "C.c_double": C.c_double, "_dp": C.POINTER(C.c_double),
+             "_ip": C.POINTER(C.c_int32), "_lp": C.POINTER(C.c_int64)}
+    ours = [(n, t) for n, t in _lib.EstepArgs._fields_]
+    assert [n for n, _ in doc_fields] == [n for n, _ in ours]
+    for (n, tname), (_, t) in zip(doc_fields, ours):
+        assert C.sizeof(types[tname]) == C.sizeof(t) and types[tname]._type_ == t._type_, n
+    header = open(os.path.join(ROOT, "include", "stm_estep.h")).read()
+    for sym in set(re.findall(r"_lib\.(stm_\w+)", text)):
+        assert re.search(r"\b" + sym + r"\s*\(", header), sym
