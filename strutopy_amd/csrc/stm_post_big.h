@@ -87,12 +87,22 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             const double my_c = (lane < nw) ? P.counts[p0 + t0 + lane] : 0.0;
             long long c0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
             // -- 1. gather: coalesced beta rows, transposed into T[topic][word]
+            {   // all 32 loads first (words beyond the document carry id 0, lanes beyond K read topic 0), then the stores
+                double gv[2][TW];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int k = lane + WAVE * r;
-                for (int j = 0; j < TW; ++j) {
-                    const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                    T[(size_t)k * TLD + j] = (k < K && j < nw) ? bT[(size_t)idx * K + k] : 0.0;
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) {
+                        const int idx = __builtin_amdgcn_readlane(my_idx, j);
+                        gv[r][j] = bT[(size_t)idx * K + (lane + WAVE * r < K ? lane + WAVE * r : 0)];
+                    }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int k = lane + WAVE * r;
+                    double2 *row = reinterpret_cast<double2 *>(T + (size_t)k * TLD);
+#pragma unroll
+                    for (int j = 0; j < TW; j += 2)
+                        row[j >> 1] = make_double2((k < K && j < nw) ? gv[r][j] : 0.0, (k < K && j + 1 < nw) ? gv[r][j + 1] : 0.0);
                 }
             }
             __syncthreads();
@@ -143,37 +153,48 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             }
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[2] += c1 - c0; c0 = c1; }
-            // -- 4. H[:, j] += b b^T restricted to the tile, lane = columns j0, j1; two rows i per round: the
-            // broadcast rows feed both column sets, and the four M elements are fetched with the rows.
-            // Lanes without a column work on the padding column n (MLD > n), so nothing here is predicated
-            // and the eight FMA chains interleave.
+            // -- 4. H += b b^T restricted to the tile, block by block on the matrix cores (upper block triangle; there are no
+            // registers for 28-36 accumulator tiles, so every 16 x 16 product goes straight into the LDS matrix, mirrored)
             {
-                const int j0 = k0 < n ? k0 : n, j1 = k1 < n ? k1 : n;
-                double o0[TW], o1[TW];
+                const int nblk = (n + 15) >> 4;
+#pragma unroll 1
+                for (int bi = 0; bi < nblk; ++bi) {
+                    const int ra = bi * 16 + fr;                 // rows of T beyond n are topic K-1 / zeros: masked at the store
+                    double fa[TW / 4];
 #pragma unroll
-                for (int w = 0; w < TW; ++w) { o0[w] = T[(size_t)j0 * TLD + w]; o1[w] = T[(size_t)j1 * TLD + w]; }
-                for (int i = 0; i < n; i += 2) {
-                    const int i1 = i + 1 < n ? i + 1 : i;
-                    const double2 *ta = reinterpret_cast<const double2 *>(T + (size_t)i * TLD);
-                    const double2 *tb = reinterpret_cast<const double2 *>(T + (size_t)i1 * TLD);
-                    double2 va[TW / 2], vb[TW / 2];
+                    for (int sk = 0; sk < TW / 4; ++sk) fa[sk] = T[(size_t)ra * TLD + sk * 4 + fq];
+#pragma unroll 1
+                    for (int bj = bi; bj < nblk; bj += 2) {      // two blocks at a time: their MFMA chains interleave, and the
+                        const bool two = bj + 1 < nblk;          // old values of M are fetched while the products are formed
+                        const int rb0 = bj * 16 + fr, rb1 = (two ? bj + 1 : bj) * 16 + fr;
+                        double fb0[TW / 4], fb1[TW / 4], m0[4], m1[4], t0[4], t1[4];
 #pragma unroll
-                    for (int w = 0; w < TW / 2; ++w) { va[w] = ta[w]; vb[w] = tb[w]; }
-                    double *ma = M + (size_t)i * MLD, *mb = M + (size_t)i1 * MLD;
-                    const double m00 = ma[j0], m01 = ma[j1], m10 = mb[j0], m11 = mb[j1];
-                    double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0, r00 = 0.0, r01 = 0.0, r10 = 0.0, r11 = 0.0;
+                        for (int sk = 0; sk < TW / 4; ++sk) { fb0[sk] = T[(size_t)rb0 * TLD + sk * 4 + fq]; fb1[sk] = T[(size_t)rb1 * TLD + sk * 4 + fq]; }
 #pragma unroll
-                    for (int w = 0; w < TW / 2; ++w) {
-                        s00 = fma(va[w].x, o0[2 * w], s00); r00 = fma(va[w].y, o0[2 * w + 1], r00);
-                        s01 = fma(va[w].x, o1[2 * w], s01); r01 = fma(va[w].y, o1[2 * w + 1], r01);
-                        s10 = fma(vb[w].x, o0[2 * w], s10); r10 = fma(vb[w].y, o0[2 * w + 1], r10);
-                        s11 = fma(vb[w].x, o1[2 * w], s11); r11 = fma(vb[w].y, o1[2 * w + 1], r11);
-                    }
-                    ma[j0] = m00 + (s00 + r00);
-                    ma[j1] = m01 + (s01 + r01);
-                    if (i + 1 < n) {   // uniform
-                        mb[j0] = m10 + (s10 + r10);
-                        mb[j1] = m11 + (s11 + r11);
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : n - 1;
+                            const int j0 = rb0 < n ? rb0 : n - 1, j1 = rb1 < n ? rb1 : n - 1;
+                            m0[r] = M[(size_t)ic * MLD + j0]; m1[r] = M[(size_t)ic * MLD + j1];
+                            t0[r] = M[(size_t)j0 * MLD + ic]; t1[r] = M[(size_t)j1 * MLD + ic];
+                        }
+                        v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0}, a1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int sk = 0; sk < TW / 4; ++sk) {
+                            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[sk], fb0[sk], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[sk], fb1[sk], a1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = bi * 16 + fq + 4 * r;
+                            if (i < n && rb0 < n) {
+                                M[(size_t)i * MLD + rb0] = m0[r] + a0[r];
+                                if (bi != bj) M[(size_t)rb0 * MLD + i] = t0[r] + a0[r];
+                            }
+                            if (two && i < n && rb1 < n) {
+                                M[(size_t)i * MLD + rb1] = m1[r] + a1[r];
+                                M[(size_t)rb1 * MLD + i] = t1[r] + a1[r];
+                            }
+                        }
                     }
                 }
             }
