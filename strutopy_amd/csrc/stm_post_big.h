@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[2] += c1 - c0; c0 = c1; }
             // -- 4. H += b b^T restricted to the tile, block by block on the matrix cores (upper block triangle; there are no
-            // registers for 28-36 accumulator tiles, so every 16 x 16 product goes straight into the LDS matrix, mirrored)
+            // registers for 28-36 accumulator tiles, so every 16 x 16 product goes straight into the LDS matrix; nothing below
+            // the block diagonal is ever read as H)
             {
                 const int nblk = (n + 15) >> 4;
 #pragma unroll 1
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                     for (int bj = bi; bj < nblk; bj += 2) {      // two blocks at a time: their MFMA chains interleave, and the
                         const bool two = bj + 1 < nblk;          // old values of M are fetched while the products are formed
                         const int rb0 = bj * 16 + fr, rb1 = (two ? bj + 1 : bj) * 16 + fr;
-                        double fb0[TW / 4], fb1[TW / 4], m0[4], m1[4], t0[4], t1[4];
+                        double fb0[TW / 4], fb1[TW / 4], m0[4], m1[4];
 #pragma unroll
                         for (int sk = 0; sk < TW / 4; ++sk) { fb0[sk] = T[(size_t)rb0 * TLD + sk * 4 + fq]; fb1[sk] = T[(size_t)rb1 * TLD + sk * 4 + fq]; }
 #pragma unroll
@@ -175,7 +176,6 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                             const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : n - 1;
                             const int j0 = rb0 < n ? rb0 : n - 1, j1 = rb1 < n ? rb1 : n - 1;
                             m0[r] = M[(size_t)ic * MLD + j0]; m1[r] = M[(size_t)ic * MLD + j1];
-                            t0[r] = M[(size_t)j0 * MLD + ic]; t1[r] = M[(size_t)j1 * MLD + ic];
                         }
                         v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0}, a1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -186,14 +186,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int i = bi * 16 + fq + 4 * r;
-                            if (i < n && rb0 < n) {
-                                M[(size_t)i * MLD + rb0] = m0[r] + a0[r];
-                                if (bi != bj) M[(size_t)rb0 * MLD + i] = t0[r] + a0[r];
-                            }
-                            if (two && i < n && rb1 < n) {
-                                M[(size_t)i * MLD + rb1] = m1[r] + a1[r];
-                                M[(size_t)rb1 * MLD + i] = t1[r] + a1[r];
-                            }
+                            if (i < n && rb0 < n) M[(size_t)i * MLD + rb0] = m0[r] + a0[r];
+                            if (two && i < n && rb1 < n) M[(size_t)i * MLD + rb1] = m1[r] + a1[r];
                         }
                     }
                 }
@@ -214,7 +208,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             if (i < n) {
                 double *mi = M + (size_t)i * MLD;
                 const double thi = sth[i];
-                for (int j = 0; j < n; ++j) {
+                for (int j = i; j < n; ++j) {   // the upper triangle is all that make_pd, the Cholesky and the dumps read
                     double h = mi[j] - Ndoc * (thi * sth[j]);
                     if (j == i) h = h - rowc[r] + Ndoc * thi;
                     const double sij = (P.siginv_diag && j != i) ? 0.0 : S[(size_t)i * n + j];
@@ -255,38 +249,101 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         o[(size_t)i * n + j] = (j == i) ? diagA[r] : (j > i ? M[(size_t)i * MLD + j] : M[(size_t)j * MLD + i]);
             }
         };
+        const int nblk = (n + 15) >> 4, nm1 = n - 1;
         int path = 0;
         bool upper = false, fail = false;
         double keep[2] = {0.0, 0.0};
         for (int attempt = 0;; ++attempt) {
             if (attempt == 2) dump(P.hess_out);
             bool ok = true;
-            for (int j = 0; j < n; ++j) {
-                double t[2] = {0.0, 0.0};
-                {   // both row sets in one loop: the broadcast row j feeds two FMAs, twelve LDS reads in flight
-                    const double *r0 = M + (size_t)(k0 < n ? k0 : n - 1) * MLD, *r1 = M + (size_t)(k1 < n ? k1 : n - 1) * MLD;
-                    const double *rj = M + (size_t)j * MLD;
-                    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-                    int l = 0;
-                    for (; l + 3 < j; l += 4) {
-                        double x[4], y[4], pj[4];
+            // blocked left-looking Cholesky, panels of 16 columns: (a) the block column minus the products of the
+            // finished panels on the matrix cores, A read from the upper triangle (transposed) and the current diagonal
+            // from sdv; (b) the panel itself with a lane's two rows in registers
+            __syncthreads();
+            sdv[lane] = diagA[0]; sdv[lane + WAVE] = diagA[1];
+            __syncthreads();
+#pragma unroll 1
+            for (int p = 0; p < nblk && ok; ++p) {
+                const int J0 = 16 * p;
+                const int bc = J0 + fr, bcc = bc < n ? bc : nm1;
+                const double *brow = M + (size_t)bcc * MLD;              // row of L_p* for the B operands (L_pk^T)
+#pragma unroll 1
+                for (int bi = p; bi < nblk; bi += 2) {
+                    const bool two = bi + 1 < nblk;
+                    const int ar0 = bi * 16 + fr, ar1 = (two ? bi + 1 : bi) * 16 + fr;
+                    const double *arow0 = M + (size_t)(ar0 < n ? ar0 : nm1) * MLD, *arow1 = M + (size_t)(ar1 < n ? ar1 : nm1) * MLD;
+                    double old0[4], old1[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { x[q] = r0[l + q]; y[q] = r1[l + q]; pj[q] = rj[l + q]; }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { a[q] = fma(x[q], pj[q], a[q]); b[q] = fma(y[q], pj[q], b[q]); }
+                    for (int r = 0; r < 4; ++r) {   // A[i][j] = M[j][i] (upper), diagonal from sdv
+                        const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
+                        const int i0c = i0 < n ? i0 : nm1, i1c = i1 < n ? i1 : nm1;
+                        old0[r] = (i0c == bcc) ? sdv[bcc] : brow[i0c];
+                        old1[r] = brow[i1c];
                     }
-                    for (; l < j; ++l) { const double pj = rj[l]; a[0] = fma(r0[l], pj, a[0]); b[0] = fma(r1[l], pj, b[0]); }
-                    if (k0 < n && k0 >= j) t[0] = ((k0 == j) ? diagA[0] : rj[k0]) - ((a[0] + a[1]) + (a[2] + a[3]));
-                    if (k1 < n && k1 >= j) t[1] = ((k1 == j) ? diagA[1] : rj[k1]) - ((b[0] + b[1]) + (b[2] + b[3]));
+                    v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0}, a1 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                    for (int k = 0; k < p; ++k) {
+                        double av0[4], av1[4], bv[4];
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) {
+                            const int kk = k * 16 + 4 * sk + fq;
+                            av0[sk] = arow0[kk]; av1[sk] = arow1[kk]; bv[sk] = brow[kk];
+                        }
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) {
+                            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[sk], bv[sk], a0, 0, 0, 0);
+                            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[sk], bv[sk], a1, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
+                        if (i0 < n && bc < n && i0 >= bc) M[(size_t)i0 * MLD + bc] = old0[r] - a0[r];
+                        if (two && i1 < n && bc < n) M[(size_t)i1 * MLD + bc] = old1[r] - a1[r];
+                    }
                 }
-                const double d = lane_bcast((j >> 6) ? t[1] : t[0], j & 63);
-                if (!(d > PIVOT_TOL * lane_bcast((j >> 6) ? diagA[1] : diagA[0], j & 63))) { ok = false; break; }
-                const double ljj = sqrt(d), rjj = 1.0 / ljj;
+                __syncthreads();
+                // (b) the panel: rows k0, k1 of the block column in registers; column j's finished entries of row J come
+                //     from the lane that owns row J (all of a panel's rows sit in one register set: J >> 6 == p >> 2)
+                double w[2][16];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int i = lane + WAVE * r, ic = i < n ? i : nm1;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) w[r][c] = M[(size_t)ic * MLD + (J0 + c < n ? J0 + c : nm1)];
+                }
+                const bool hi = (p >> 2) != 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {   // no early exit (the steps must unroll: w is indexed by j): a failed pivot turns the rest off
+                    const int J = J0 + j;
+                    if (ok && J < n) {
+                        const int ol = J & 63;
+                        double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
+#pragma unroll
+                        for (int l = 0; l < j; ++l) {
+                            const double x = lane_bcast(hi ? w[1][l] : w[0][l], ol);
+                            if (l & 1) { s1[0] = fma(w[0][l], x, s1[0]); s1[1] = fma(w[1][l], x, s1[1]); }
+                            else { s0[0] = fma(w[0][l], x, s0[0]); s0[1] = fma(w[1][l], x, s0[1]); }
+                        }
+                        const double t0 = w[0][j] - (s0[0] + s1[0]), t1 = w[1][j] - (s0[1] + s1[1]);
+                        const double d = lane_bcast(hi ? t1 : t0, ol);
+                        if (!(d > PIVOT_TOL * lane_bcast(hi ? diagA[1] : diagA[0], ol))) {
+                            ok = false;
+                        } else {
+                            const double ljj = sqrt(d), rjj = 1.0 / ljj;
+                            if (k0 == J) Ldiag[0] = ljj;
+                            if (k1 == J) Ldiag[1] = ljj;
+                            w[0][j] = t0 * rjj; w[1][j] = t1 * rjj;
+                        }
+                    }
+                }
+                if (!ok) break;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int i = lane + WAVE * r;
-                    if (i == j) Ldiag[r] = ljj;
-                    if (i < n && i > j) M[(size_t)i * MLD + j] = t[r] * rjj;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (i < n && i > J0 + c) M[(size_t)i * MLD + J0 + c] = w[r][c];
                 }
                 __syncthreads();
             }
@@ -352,7 +409,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         P.bound[doc] = ll + (-det) - 0.5 * q - P.sigmaentropy;
 
         if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
-        // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066): R = L^-T into the upper triangle
+        // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066): X = L^-1 blocked by 16 and IN PLACE of L
+        // (lower triangle and diagonal of M), then nu = X^T X -- the scheme of post_kernel with run-time block counts
         double Rdiag[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -360,91 +418,166 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             srd[lane + WAVE * r] = (lane + WAVE * r < n) ? Rdiag[r] : 0.0;
         }
         __syncthreads();
+        long long ti[3] = {0, 0, 0};
+        if (P.prof) ti[0] = (long long)__builtin_readcyclecounter();
         if (!upper) {
-            for (int i = n - 2; i >= 0; --i) {
-                double t[2] = {0.0, 0.0};
-                {   // both columns in one loop over the rows l of R below i (L[l][i] is a broadcast read)
-                    const int c0 = k0 < n ? k0 : n - 1, c1 = k1 < n ? k1 : n - 1;
-                    const double *ci = M + i, *p0 = M + c0, *p1 = M + c1;
-                    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-                    a[0] = M[(size_t)c0 * MLD + i] * Rdiag[0];   // the l == c terms
-                    b[0] = M[(size_t)c1 * MLD + i] * Rdiag[1];
-                    int l = i + 1;
-                    for (; l + 3 < n - 1; l += 4) {
-                        double u[4], x[4], y[4];
+            // (I) the diagonal blocks, four per pass, lane = (block, column c):
+            //     X[i][c] = -(sum_{c<=l<i} L[i][l] X[l][c]) / L[i][i], row by row; a lane reads back only its own column
+#pragma unroll 1
+            for (int pass = 0; pass * WAVE < n; ++pass) {
+                const int gl = lane + WAVE * pass;
+                const int c = lane & 15, base = gl & ~15;
+                const int rows = n - base < 16 ? n - base : 16;    // rows of this lane's block (<= 0: no block)
+                const int rb = base < n ? base : 0;                 // lanes beyond the matrix shadow block 0 (nothing is stored)
+                const int rlast = (rows > 0 ? rows : 16) - 1;
+                double *xc = M + (size_t)rb * MLD + (base < n ? gl : c);
+                if (base < n && c < rows) xc[(size_t)c * MLD] = srd[gl];   // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
+#pragma unroll 1
+                for (int i = 1; i < 16; ++i) {
+                    const int ir = i < rlast ? i : rlast;           // clamped: reads stay inside the matrix
+                    const double *lrow = M + (size_t)(rb + ir) * MLD + rb;
+                    double lv[16], xv[16];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            u[q] = ci[(size_t)(l + q) * MLD]; x[q] = p0[(size_t)(l + q) * MLD]; y[q] = p1[(size_t)(l + q) * MLD];
+                    for (int l = 0; l < 16; ++l) {
+                        lv[l] = lrow[l];
+                        xv[l] = xc[(size_t)(l < rlast ? l : rlast) * MLD];
+                    }
+                    const double rd = srd[rb + ir];
+                    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 16; l += 2) {
+                        t0 = fma(lv[l], (l >= c && l < i) ? xv[l] : 0.0, t0);
+                        t1 = fma(lv[l + 1], (l + 1 >= c && l + 1 < i) ? xv[l + 1] : 0.0, t1);
+                    }
+                    // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
+                    if (base < n && i > c && i < rows) xc[(size_t)i * MLD] = -(t0 + t1) * rd;
+                }
+            }
+            __syncthreads();
+            if (P.prof) ti[1] = (long long)__builtin_readcyclecounter();
+            // (II) X_ij = -X_ii (sum_{j<=k<i} L_ik X_kj) on the matrix cores, block columns left to right, block rows top
+            //      down (X_ij takes the place of L_ij, which no later product reads); the inner sum leaves the MFMA in the
+            //      register layout its B operand wants
+#pragma unroll 1
+            for (int bj = 0; bj + 1 < nblk; ++bj) {
+#pragma unroll 1
+                for (int bi = bj + 1; bi < nblk; ++bi) {
+                    const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
+                    const double *arow = M + (size_t)arc * MLD;           // row of L_i* / X_ii for the A operands
+                    const int bc = bj * 16 + fr;
+                    v4d sacc0 = (v4d){0.0, 0.0, 0.0, 0.0}, sacc1 = (v4d){0.0, 0.0, 0.0, 0.0};
+                    int k = bj;
+#pragma unroll 1
+                    for (; k + 1 < bi; k += 2) {   // two k blocks in flight, separate accumulators (summed below)
+                        double av[8], bv[8];
+#pragma unroll
+                        for (int sk = 0; sk < 8; ++sk) {
+                            const int kk = k * 16 + 4 * sk + fq;           // < 16 (nblk - 1) <= n: full blocks only
+                            av[sk] = arow[kk];                              // L_ik[fr][4 sk + fq]
+                            bv[sk] = M[(size_t)kk * MLD + bc];              // X_kj[4 sk + fq][fr]
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            a[q] = fma(u[q], (l + q < c0) ? x[q] : 0.0, a[q]);
-                            b[q] = fma(u[q], (l + q < c1) ? y[q] : 0.0, b[q]);
+                        for (int sk = 0; sk < 4; ++sk) {
+                            const int kk = k * 16 + 4 * sk + fq;
+                            const double a = (ar < n) ? av[sk] : 0.0, a2 = (ar < n) ? av[sk + 4] : 0.0;
+                            const double bb = (k > bj || bc <= kk) ? bv[sk] : 0.0;   // the diagonal block of X is lower triangular
+                            sacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, sacc0, 0, 0, 0);
+                            sacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bv[sk + 4], sacc1, 0, 0, 0);
                         }
                     }
-                    for (; l < n - 1; ++l) {
-                        const double u = ci[(size_t)l * MLD];
-                        a[0] = fma(u, (l < c0) ? p0[(size_t)l * MLD] : 0.0, a[0]);
-                        b[0] = fma(u, (l < c1) ? p1[(size_t)l * MLD] : 0.0, b[0]);
-                    }
-                    if (k0 < n && k0 > i) t[0] = -((a[0] + a[1]) + (a[2] + a[3]));
-                    if (k1 < n && k1 > i) t[1] = -((b[0] + b[1]) + (b[2] + b[3]));
-                }
-                const double rii = srd[i];
+                    if (k < bi) {
+                        double av[4], bv[4];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int c = lane + WAVE * r;
-                    if (c < n && c > i) M[(size_t)i * MLD + c] = t[r] * rii;
+                        for (int sk = 0; sk < 4; ++sk) {
+                            const int kk = k * 16 + 4 * sk + fq;
+                            av[sk] = arow[kk];
+                            bv[sk] = M[(size_t)kk * MLD + bc];
+                        }
+#pragma unroll
+                        for (int sk = 0; sk < 4; ++sk) {
+                            const int kk = k * 16 + 4 * sk + fq;
+                            const double a = (ar < n) ? av[sk] : 0.0;
+                            const double bb = (k > bj || bc <= kk) ? bv[sk] : 0.0;
+                            sacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, sacc0, 0, 0, 0);
+                        }
+                    }
+                    const v4d sacc = sacc0 + sacc1;
+                    double xv[4];
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) {
+                        const int ac = bi * 16 + 4 * sk + fq;
+                        xv[sk] = arow[ac < n ? ac : nm1];                   // X_ii[fr][4 sk + fq]
+                    }
+                    v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) {
+                        const int ac = bi * 16 + 4 * sk + fq;
+                        const double a = (ac <= ar && ar < n) ? xv[sk] : 0.0;
+                        dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sacc[sk], dacc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = bi * 16 + fq + 4 * r;
+                        if (row < n) M[(size_t)row * MLD + bc] = -dacc[r];
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
         }
         __syncthreads();
         if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
-        // nu[i][j] = sum_{l >= max(i,j)} R[i][l] R[j][l], lane = columns j0, j1; sigma_ss += nu (stm.py:582).
-        // The diagonal of M is free by now (A's and L's diagonals live in registers): R[x][x] goes there so the
-        // loop has no special cases; row i of R is a broadcast read, rows j0 / j1 are the lane's own.
+        if (P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = tp[6] - ti[1]; }
+        // nu = R R^T = X^T X (sigma_ss += nu, stm.py:582), one block column bj of output tiles (bi <= bj) at a time on the
+        // matrix cores: nu[i][j] = sum_{l >= 16 bj} X[l][i] X[l][j]; fragment X[s4 + fq][b*16 + fr], zero above the diagonal
+        double *nu_doc = P.nu_out ? P.nu_out + (size_t)doc * n * n : nullptr;
+        if (upper) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-            if (lane + WAVE * r < n) M[(size_t)(lane + WAVE * r) * MLD + lane + WAVE * r] = Rdiag[r];
-        __syncthreads();
-        {
-            const int j0 = k0 < n ? k0 : n - 1, j1 = k1 < n ? k1 : n - 1;
-            const double *q0 = M + (size_t)j0 * MLD, *q1 = M + (size_t)j1 * MLD;
-            for (int i = 0; i < n; ++i) {
-                double v0, v1;
-                if (upper) {
-                    v0 = (k0 == i) ? Rdiag[0] * Rdiag[0] : 0.0;
-                    v1 = (k1 == i) ? Rdiag[1] * Rdiag[1] : 0.0;
-                } else {
-                    const double *qi = M + (size_t)i * MLD;
-                    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-                    int l = i;
-                    for (; l + 3 < n; l += 4) {
-                        double u[4], x[4], y[4];
+            for (int r = 0; r < 2; ++r) {
+                const int i = lane + WAVE * r;
+                if (i < n) {
+                    const double v = Rdiag[r] * Rdiag[r];
+                    unsafeAtomicAdd(sig_acc + (size_t)i * n + i, v);
+                    if (nu_doc)
+                        for (int j = 0; j < n; ++j) nu_doc[(size_t)i * n + j] = (j == i) ? v : 0.0;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int bj = 0; bj < nblk; ++bj) {
+                const int rj = bj * 16 + fr, rjc = rj < n ? rj : nm1;
+                v4d acc[8];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) { u[q] = qi[l + q]; x[q] = q0[l + q]; y[q] = q1[l + q]; }
+                for (int b = 0; b < 8; ++b) acc[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                for (int s4 = bj * 16; s4 < n; s4 += 4) {
+                    const int col = s4 + fq, colc = col < n ? col : nm1;
+                    const double *xr = M + (size_t)colc * MLD;
+                    double f[8];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            a[q] = fma(u[q], (l + q >= j0) ? x[q] : 0.0, a[q]);
-                            b[q] = fma(u[q], (l + q >= j1) ? y[q] : 0.0, b[q]);
+                    for (int b = 0; b < 8; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
+                    const double fb = (col < n && rj < n && col >= rj) ? f[7] : 0.0;   // f[7] is always block bj's own fragment
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        if (b > bj) break;
+                        const double fa = (b == bj) ? fb : ((col < n) ? f[b] : 0.0);
+                        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[b], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    if (b > bj) break;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = b * 16 + fq + 4 * r, j = rj;
+                        if (i < n && j < n) {
+                            unsafeAtomicAdd(sig_acc + (size_t)i * n + j, acc[b][r]);
+                            if (b != bj) unsafeAtomicAdd(sig_acc + (size_t)j * n + i, acc[b][r]);
+                            if (nu_doc) {
+                                nu_doc[(size_t)i * n + j] = acc[b][r];
+                                nu_doc[(size_t)j * n + i] = acc[b][r];
+                            }
                         }
                     }
-                    for (; l < n; ++l) {
-                        const double u = qi[l];
-                        a[0] = fma(u, (l >= j0) ? q0[l] : 0.0, a[0]);
-                        b[0] = fma(u, (l >= j1) ? q1[l] : 0.0, b[0]);
-                    }
-                    v0 = (a[0] + a[1]) + (a[2] + a[3]);
-                    v1 = (b[0] + b[1]) + (b[2] + b[3]);
-                }
-                if (k0 < n) {
-                    unsafeAtomicAdd(sig_acc + (size_t)i * n + k0, v0);
-                    if (P.nu_out) P.nu_out[(size_t)doc * n * n + (size_t)i * n + k0] = v0;
-                }
-                if (k1 < n) {
-                    unsafeAtomicAdd(sig_acc + (size_t)i * n + k1, v1);
-                    if (P.nu_out) P.nu_out[(size_t)doc * n * n + (size_t)i * n + k1] = v1;
                 }
             }
         }
