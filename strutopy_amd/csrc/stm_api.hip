@@ -597,9 +597,12 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
                        : (nb <= 1 ? stm::post_kernel<1, 0, false> : nb == 2 ? stm::post_kernel<2, 0, false>
                           : nb == 3 ? stm::post_kernel<3, 0, false> : stm::post_kernel<4, 0, false>);
         const bool big = K > stm::PT;   // two topics per lane, VALU only (stm_post_big.h)
-        pp.MLD = big ? ((n + 1) | 1) : stm::post_mld(n);   // big: odd, with at least one padding column
-        const PostFn pfn = big ? stm::post_big_kernel : pf;
-        const size_t lds = (big ? stm::post_big_lds_doubles(n, pp.MLD) : stm::post_lds_doubles(n, pp.MLD, K)) * sizeof(double);
+        pp.MLD = big ? stm::post_big_mld(n) : stm::post_mld(n);
+        const int nbb = (n + 15) / 16;
+        const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
+                           : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
+        const PostFn pfn = big ? pfb : pf;
+        const size_t lds = (big ? stm::post_big_lds_doubles(n) : stm::post_lds_doubles(n, pp.MLD, K)) * sizeof(double);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, 64, lds));

@@ -7,20 +7,28 @@
 // per CU and no room for the MFMA accumulator sets of the K <= 64 kernel.  This is the coverage path
 // for BASELINE config 4 (K = 100); it is not tuned.
 #pragma once
+#include <type_traits>
 #include "stm_post.h"
 
 namespace stm {
 
 constexpr int BT = 128;   // topics padded to 128
 
-inline size_t post_big_lds_doubles(int n, int MLD) { return (((size_t)n * MLD + 1) & ~(size_t)1) + (size_t)BT * TLD + 4 * BT + 4 * TW; }
+// the matrix is padded to whole 16 x 16 blocks, leading dimension 16 NB + 1 (odd: lane-strided column walks are conflict free)
+inline int post_big_mld(int n) { return 16 * ((n + 15) / 16) + 1; }
+inline size_t post_big_lds_doubles(int n) {
+    const size_t nb = (n + 15) / 16;
+    return ((16 * nb * (16 * nb + 1) + 1) & ~(size_t)1) + (size_t)BT * TLD + 4 * BT + 4 * TW;
+}
 
+template <int NB>   // NB = ceil((K-1) / 16) block rows: 4 .. 8
 __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
     extern __shared__ __attribute__((aligned(16))) double big_lds[];
-    const int lane = threadIdx.x;
-    const int K = P.K, n = P.n, MLD = P.MLD;
-    double *M = big_lds;                        // [n][MLD]: H, then A (upper) / L (lower) / R (upper)
-    double *T = M + (((size_t)n * MLD + 1) & ~(size_t)1);   // [BT][TLD] word tile, topic-major (16-byte aligned rows)
+    int lane = threadIdx.x;
+    const int K = P.K, n = P.n;
+    constexpr int MLD = 16 * NB + 1, MROWS = 16 * NB;   // compile-time: tile addresses are immediates
+    double *M = big_lds;                        // [16 NB][MLD]: H, then A (upper) / L, then X = L^-1 (lower)
+    double *T = M + (((size_t)MROWS * MLD + 1) & ~(size_t)1);   // [BT][TLD] word tile, topic-major (16-byte aligned rows)
     double *sex = T + (size_t)BT * TLD;         // exp(eta~)
     double *sth = sex + BT;                     // stable_softmax(eta~)
     double *sdv = sth + BT;                     // eta - mu (dense siginv only)
@@ -28,10 +36,19 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
     double *wpar = srd + BT;                    // per word of the tile: { sqrt(c), S, 1/S, sqrt(c)/S }
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int k0 = lane, k1 = lane + WAVE;      // this lane's two topics / rows
+    constexpr int NT = NB * (NB + 1) / 2;
+    int fr = lane & 15, fq = lane >> 4;
+    int k0 = lane, k1 = lane + WAVE;            // this lane's two topics / rows
+    // The lane id is re-read behind an opaque move at the start of every phase: otherwise each lane-dependent LDS address
+    // of the unrolled tile code is hoisted out of the document loop as a loop invariant, and lives in scratch memory.
+    auto relane = [&]() __attribute__((always_inline)) {
+        int l = threadIdx.x;
+        asm volatile("" : "+v"(l));
+        lane = l; fr = l & 15; fq = l >> 4; k0 = l; k1 = l + WAVE;
+    };
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
+        relane();
         const int64_t ticket = P.first + tk;
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
@@ -72,38 +89,40 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             sex[k] = exv[r];
             sth[k] = (k < K) ? thsv[r] : 0.0;
         }
-        for (int q = lane; q < n * MLD; q += WAVE) M[q] = 0.0;
+        for (int q = lane; q < MROWS * MLD; q += WAVE) M[q] = 0.0;
         for (int q = lane; q < BT * TLD; q += WAVE) T[q] = 0.0;
         __syncthreads();
 
         if (P.prof) tp[1] = (long long)__builtin_readcyclecounter();
+        relane();
         double csum = 0.0, ll = 0.0, rowc[2] = {0.0, 0.0};
         bool bad = false;
         const int kc = (K + 3) >> 2;  // topics per quarter in the per-word sums (<= 32)
         long long tq[5] = {0, 0, 0, 0, 0};
+        v4d hacc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) hacc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
         for (int t0 = 0; t0 < Nd; t0 += TW) {
+            relane();
             const int nw = Nd - t0 < TW ? Nd - t0 : TW;
             const int my_idx = (lane < nw) ? P.indices[p0 + t0 + lane] : 0;
             const double my_c = (lane < nw) ? P.counts[p0 + t0 + lane] : 0.0;
             long long c0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
             // -- 1. gather: coalesced beta rows, transposed into T[topic][word]
-            {   // all 32 loads first (words beyond the document carry id 0, lanes beyond K read topic 0), then the stores
-                double gv[2][TW];
+            // a row set's 16 loads first (words beyond the document carry id 0, lanes beyond K read topic 0), then its stores
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r) {
+                const int k = lane + WAVE * r;
+                double gv[TW];
 #pragma unroll
-                    for (int j = 0; j < TW; ++j) {
-                        const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                        gv[r][j] = bT[(size_t)idx * K + (lane + WAVE * r < K ? lane + WAVE * r : 0)];
-                    }
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int k = lane + WAVE * r;
-                    double2 *row = reinterpret_cast<double2 *>(T + (size_t)k * TLD);
-#pragma unroll
-                    for (int j = 0; j < TW; j += 2)
-                        row[j >> 1] = make_double2((k < K && j < nw) ? gv[r][j] : 0.0, (k < K && j + 1 < nw) ? gv[r][j + 1] : 0.0);
+                for (int j = 0; j < TW; ++j) {
+                    const int idx = __builtin_amdgcn_readlane(my_idx, j);
+                    gv[j] = bT[(size_t)idx * K + (k < K ? k : 0)];
                 }
+                double2 *row = reinterpret_cast<double2 *>(T + (size_t)k * TLD);
+#pragma unroll
+                for (int j = 0; j < TW; j += 2)
+                    row[j >> 1] = make_double2((k < K && j < nw) ? gv[j] : 0.0, (k < K && j + 1 < nw) ? gv[j + 1] : 0.0);
             }
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[0] += c1 - c0; c0 = c1; }
@@ -153,44 +172,22 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             }
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[2] += c1 - c0; c0 = c1; }
-            // -- 4. H += b b^T restricted to the tile, block by block on the matrix cores (upper block triangle; there are no
-            // registers for 28-36 accumulator tiles, so every 16 x 16 product goes straight into the LDS matrix; nothing below
-            // the block diagonal is ever read as H)
+            // -- 4. H += b b^T restricted to the tile on the matrix cores: the NB (NB + 1) / 2 accumulator tiles of the upper
+            // block triangle stay in registers for the whole document (one wave per SIMD owns the full 512-register file)
             {
-                const int nblk = (n + 15) >> 4;
-#pragma unroll 1
-                for (int bi = 0; bi < nblk; ++bi) {
-                    const int ra = bi * 16 + fr;                 // rows of T beyond n are topic K-1 / zeros: masked at the store
-                    double fa[TW / 4];
+                double f[NB][TW / 4];
 #pragma unroll
-                    for (int sk = 0; sk < TW / 4; ++sk) fa[sk] = T[(size_t)ra * TLD + sk * 4 + fq];
-#pragma unroll 1
-                    for (int bj = bi; bj < nblk; bj += 2) {      // two blocks at a time: their MFMA chains interleave, and the
-                        const bool two = bj + 1 < nblk;          // old values of M are fetched while the products are formed
-                        const int rb0 = bj * 16 + fr, rb1 = (two ? bj + 1 : bj) * 16 + fr;
-                        double fb0[TW / 4], fb1[TW / 4], m0[4], m1[4];
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                        for (int sk = 0; sk < TW / 4; ++sk) { fb0[sk] = T[(size_t)rb0 * TLD + sk * 4 + fq]; fb1[sk] = T[(size_t)rb1 * TLD + sk * 4 + fq]; }
+                    for (int sk = 0; sk < TW / 4; ++sk) f[b][sk] = T[(size_t)(b * 16 + fr) * TLD + sk * 4 + fq];   // rows beyond n: masked at the store
+                int t = 0;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : n - 1;
-                            const int j0 = rb0 < n ? rb0 : n - 1, j1 = rb1 < n ? rb1 : n - 1;
-                            m0[r] = M[(size_t)ic * MLD + j0]; m1[r] = M[(size_t)ic * MLD + j1];
-                        }
-                        v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0}, a1 = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-                        for (int sk = 0; sk < TW / 4; ++sk) {
-                            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[sk], fb0[sk], a0, 0, 0, 0);
-                            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[sk], fb1[sk], a1, 0, 0, 0);
-                        }
+                    for (int bj = bi; bj < NB; ++bj, ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = bi * 16 + fq + 4 * r;
-                            if (i < n && rb0 < n) M[(size_t)i * MLD + rb0] = m0[r] + a0[r];
-                            if (two && i < n && rb1 < n) M[(size_t)i * MLD + rb1] = m1[r] + a1[r];
-                        }
-                    }
-                }
+                        for (int sk = 0; sk < TW / 4; ++sk)
+                            hacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi][sk], f[bj][sk], hacc[t], 0, 0, 0);
             }
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[3] += c1 - c0; c0 = c1; }
@@ -201,6 +198,19 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
 
+        {   // b b^T leaves the registers: upper block triangle of M
+            int t = 0;
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                for (int bj = bi; bj < NB; ++bj, ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
+                        M[(size_t)i * MLD + j] = hacc[t][r];   // padding rows / columns take whatever topic K-1 and the zeros give
+                    }
+        }
+        __syncthreads();
         // ---- H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv (lane = row)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         __syncthreads();
 
         if (P.prof) tp[3] = (long long)__builtin_readcyclecounter();
+        relane();
         // ---- PD ladder around one Cholesky (the upper triangle keeps A, L goes to the strict lower triangle)
         double diagA[2], Ldiag[2] = {1.0, 1.0};
 #pragma unroll
@@ -249,7 +260,9 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         o[(size_t)i * n + j] = (j == i) ? diagA[r] : (j > i ? M[(size_t)i * MLD + j] : M[(size_t)j * MLD + i]);
             }
         };
-        const int nblk = (n + 15) >> 4, nm1 = n - 1;
+        constexpr int nblk = NB;
+        const int nm1 = n - 1;
+        long long tc[3] = {0, 0, 0};
         int path = 0;
         bool upper = false, fail = false;
         double keep[2] = {0.0, 0.0};
@@ -262,9 +275,13 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             __syncthreads();
             sdv[lane] = diagA[0]; sdv[lane + WAVE] = diagA[1];
             __syncthreads();
+            // every pivot that passes lies in (32 eps, 1] x its diagonal entry (up to rounding): the range test of
+            // sqrt_and_rsqrt can be made on the diagonal, once
+            const bool fast_sqrt = !wave_any((k0 < n && !(diagA[0] > 1e-260 && diagA[0] < 1e270)) || (k1 < n && !(diagA[1] > 1e-260 && diagA[1] < 1e270)));
 #pragma unroll 1
             for (int p = 0; p < nblk && ok; ++p) {
                 const int J0 = 16 * p;
+                long long cc0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
                 const int bc = J0 + fr, bcc = bc < n ? bc : nm1;
                 const double *brow = M + (size_t)bcc * MLD;              // row of L_p* for the B operands (L_pk^T)
 #pragma unroll 1
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                     }
                 }
                 __syncthreads();
+                if (P.prof) { long long c1 = __builtin_readcyclecounter(); tc[0] += c1 - cc0; cc0 = c1; }
                 // (b) the panel: rows k0, k1 of the block column in registers; column j's finished entries of row J come
                 //     from the lane that owns row J (all of a panel's rows sit in one register set: J >> 6 == p >> 2)
                 double w[2][16];
@@ -312,31 +330,50 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
                     for (int c = 0; c < 16; ++c) w[r][c] = M[(size_t)ic * MLD + (J0 + c < n ? J0 + c : nm1)];
                 }
+                // Right-looking inside the panel and free of branches, so that the updates of the later columns fill the
+                // latency of the square root chain: a failed pivot (or a column beyond n) only raises a flag, and whatever
+                // the remaining steps compute from it is never stored.
                 const bool hi = (p >> 2) != 0;
+                const int ol0 = J0 & 63;
+                auto panel = [&](auto fastc) __attribute__((always_inline)) {
+                    bool bad = false;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {   // no early exit (the steps must unroll: w is indexed by j): a failed pivot turns the rest off
-                    const int J = J0 + j;
-                    if (ok && J < n) {
-                        const int ol = J & 63;
-                        double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
-#pragma unroll
-                        for (int l = 0; l < j; ++l) {
-                            const double x = lane_bcast(hi ? w[1][l] : w[0][l], ol);
-                            if (l & 1) { s1[0] = fma(w[0][l], x, s1[0]); s1[1] = fma(w[1][l], x, s1[1]); }
-                            else { s0[0] = fma(w[0][l], x, s0[0]); s0[1] = fma(w[1][l], x, s0[1]); }
-                        }
-                        const double t0 = w[0][j] - (s0[0] + s1[0]), t1 = w[1][j] - (s0[1] + s1[1]);
-                        const double d = lane_bcast(hi ? t1 : t0, ol);
-                        if (!(d > PIVOT_TOL * lane_bcast(hi ? diagA[1] : diagA[0], ol))) {
-                            ok = false;
+                    for (int j = 0; j < 16; ++j) {
+                        const int J = J0 + j;
+                        const double d = lane_bcast(hi ? w[1][j] : w[0][j], ol0 + j);
+                        const double dA = lane_bcast(hi ? diagA[1] : diagA[0], ol0 + j);
+                        bad |= (J < n) && !(d > PIVOT_TOL * dA);
+                        double ljj, rjj;
+                        if constexpr (decltype(fastc)::value) {   // sqrt_and_rsqrt without its range test (made on diagA, once)
+                            const double y = __builtin_amdgcn_rsq(d);
+                            double g = d * y, h = 0.5 * y;
+                            double e = fma(-h, g, 0.5);
+                            g = fma(g, e, g); h = fma(h, e, h);
+                            e = fma(-h, g, 0.5);
+                            g = fma(g, e, g); h = fma(h, e, h);
+                            const double rr = fma(-g, g, d);
+                            g = fma(rr, h, g);
+                            e = fma(-h, g, 0.5);
+                            h = fma(h, e, h);
+                            ljj = g; rjj = h + h;
                         } else {
-                            const double ljj = sqrt(d), rjj = 1.0 / ljj;
-                            if (k0 == J) Ldiag[0] = ljj;
-                            if (k1 == J) Ldiag[1] = ljj;
-                            w[0][j] = t0 * rjj; w[1][j] = t1 * rjj;
+                            ljj = sqrt(d); rjj = 1.0 / ljj;
+                        }
+                        if (k0 == J) Ldiag[0] = ljj;
+                        if (k1 == J) Ldiag[1] = ljj;
+                        w[0][j] *= rjj; w[1][j] *= rjj;
+#pragma unroll
+                        for (int c = j + 1; c < 16; ++c) {
+                            const double x = lane_bcast(hi ? w[1][j] : w[0][j], ol0 + c);   // L[J0 + c][J]
+                            w[0][c] = fma(-w[0][j], x, w[0][c]);
+                            w[1][c] = fma(-w[1][j], x, w[1][c]);
                         }
                     }
-                }
+                    return bad;
+                };
+                if (P.prof) { long long c1 = __builtin_readcyclecounter(); tc[1] += c1 - cc0; cc0 = c1; }
+                if (fast_sqrt ? panel(std::true_type{}) : panel(std::false_type{})) ok = false;
+                if (P.prof) { long long c1 = __builtin_readcyclecounter(); tc[2] += c1 - cc0; cc0 = c1; }
                 if (!ok) break;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
@@ -409,6 +446,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         P.bound[doc] = ll + (-det) - 0.5 * q - P.sigmaentropy;
 
         if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
+        relane();
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066): X = L^-1 blocked by 16 and IN PLACE of L
         // (lower triangle and diagonal of M), then nu = X^T X -- the scheme of post_kernel with run-time block counts
         double Rdiag[2];
@@ -526,7 +564,9 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         }
         __syncthreads();
         if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
+        relane();
         if (P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = tp[6] - ti[1]; }
+        if (P.prof && lane == 0) { P.prof[doc * 40 + 30] = tc[0]; P.prof[doc * 40 + 31] = tc[2]; P.prof[doc * 40 + 23] = tc[1]; }
         // nu = R R^T = X^T X (sigma_ss += nu, stm.py:582), one block column bj of output tiles (bi <= bj) at a time on the
         // matrix cores: nu[i][j] = sum_{l >= 16 bj} X[l][i] X[l][j]; fragment X[s4 + fq][b*16 + fr], zero above the diagonal
         double *nu_doc = P.nu_out ? P.nu_out + (size_t)doc * n * n : nullptr;

@@ -28,6 +28,8 @@ for it in range(2):
     if True:
         print("   post tile phases cycles/doc: gather %.0f sums %.0f scatter %.0f H-acc %.0f" % tuple(out[:, 24:28].mean(0)))
     print("   post inverse phases cycles/doc: diag blocks %.0f, MFMA blocks %.0f, remainder row %.0f, pre %.0f" % tuple(out[:, 28:32].mean(0)))
+    if KK > 64:   # post_big_kernel reuses the last two slots (and slot 23) for its Cholesky
+        print("   post_big Cholesky cycles/doc: block column updates %.0f, panel loads %.0f, panels %.0f" % (out[:, 30].mean(), out[:, 23].mean(), out[:, 31].mean()))
     for i, nm in enumerate(names):
         c, v = out[:, 8 + i].mean(), out[:, 24 + i].mean()
         if v > 0:
