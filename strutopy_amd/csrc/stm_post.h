@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     constexpr int NT = NB * (NB + 1) / 2;
     constexpr int R0 = 16 * NB;   // index of the remainder row (REM == 1)
     extern __shared__ __attribute__((aligned(16))) double post_lds[];
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
     const int K = P.K, n = P.n, MLD = P.MLD;
     double *T = post_lds;  // [PT][TLD]
     double *M = post_lds;  // [n][MLD] (after the word loop)
@@ -115,8 +115,15 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     double *sdv = vec + KV;       // ... bound: eta - mu broadcast (dense siginv only)
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
-    const bool isn = lane < n, isk = lane < K;
-    const int fr = lane & 15, fq = lane >> 4;  // MFMA fragment coordinates
+    bool isn = lane < n, isk = lane < K;
+    int fr = lane & 15, fq = lane >> 4;  // MFMA fragment coordinates
+    // The lane id is re-read behind an opaque move at the start of every phase: otherwise the lane-dependent LDS
+    // addresses of the unrolled tile code are hoisted out of the document loop as invariants and live in scratch memory.
+    auto relane = [&]() __attribute__((always_inline)) {
+        int l = threadIdx.x;
+        asm volatile("" : "+v"(l));
+        lane = l; isn = l < n; isk = l < K; fr = l & 15; fq = l >> 4;
+    };
 
     v4d acc_nu[NT];
 #pragma unroll
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
     double nu_rem = 0.0;   // REM: running sum of nu[lane][R0]
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
+        relane();
         const int64_t ticket = P.first + tk;
         // the document header through the scalar cache (uniform, constant for the kernel's lifetime)
         const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         STM_POST_SYNC();
 
         if (P.prof) tp[1] = (long long)__builtin_readcyclecounter();
+        relane();
         double csum = 0.0, ll = 0.0, rowc = 0.0;
         bool bad = false;
         v4d acc[NT];
@@ -293,6 +302,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         }
         if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
         if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
+        relane();
         if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
@@ -352,6 +362,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         STM_POST_SYNC();
 
         if (P.prof) tp[3] = (long long)__builtin_readcyclecounter();
+        relane();
         // ---- PD handling.  diagA: current diagonal of A (lane i); off-diagonals of A are read
         // from the upper triangle of M, which Cholesky never writes.
         double diagA = isn ? M[(size_t)lane * MLD + lane] : 1.0;
@@ -522,6 +533,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         if (P.debug_flags & 4) continue;
 
         if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
+        relane();
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066)
         const double Rdiag = 1.0 / Ldiag;
         if (isn) srd[lane] = Rdiag;
@@ -637,6 +649,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         }
         STM_POST_SYNC();
         if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
+        relane();
         if (P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = ti[2] - ti[1]; P.prof[doc * 40 + 30] = tp[6] - ti[2]; P.prof[doc * 40 + 31] = ti[0] - tp[5]; }
         // nu = R R^T = X^T X on the matrix cores, accumulated straight into the workgroup's running sum
         // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq] = X[s4 + fq][b*16 + fr], zero below the diagonal
