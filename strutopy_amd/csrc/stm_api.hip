@@ -603,6 +603,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
                            : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
         const PostFn pfn = big ? pfb : pf;
         const size_t lds = (big ? stm::post_big_lds_doubles(n) : stm::post_lds_doubles(n, pp.MLD, K)) * sizeof(double);
+        pp.lds_doubles = (int)(lds / sizeof(double));
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, 64, lds));

@@ -51,7 +51,9 @@ struct PostParams {
     int32_t *pd_path;
     int32_t *err_flag;
     double *hess_out, *chol_out, *nu_out;  // optional [N][n][n] dumps (nullable)
-    int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky
+    int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky;
+                           // 16 (tests): NaN into the whole LDS allocation before every document
+    int lds_doubles;       // size of the dynamic LDS allocation
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
     int MLD;               // leading dimension of the LDS matrix (odd, >= n)
@@ -132,6 +134,11 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
         relane();
+        if (P.debug_flags & 16) {   // nothing may depend on what an earlier document or kernel left in the LDS
+            STM_POST_SYNC();
+            for (int q = lane; q < P.lds_doubles; q += WAVE) post_lds[q] = __builtin_nan("");
+            STM_POST_SYNC();
+        }
         const int64_t ticket = P.first + tk;
         // the document header through the scalar cache (uniform, constant for the kernel's lifetime)
         const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
@@ -569,8 +576,10 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
                     for (int l = 0; l < 16; l += 2) {
-                        t0 = fma(lv[l], (l >= c && l < i) ? xv[l] : 0.0, t0);
-                        t1 = fma(lv[l + 1], (l + 1 >= c && l + 1 < i) ? xv[l + 1] : 0.0, t1);
+                        // both factors are selected: the row of L runs into columns nobody ever wrote (0 x NaN is NaN)
+                        const bool m0 = l >= c && l < i, m1 = l + 1 >= c && l + 1 < i;
+                        t0 = fma(m0 ? lv[l] : 0.0, m0 ? xv[l] : 0.0, t0);
+                        t1 = fma(m1 ? lv[l + 1] : 0.0, m1 ? xv[l + 1] : 0.0, t1);
                     }
                     // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
                     if (base < n && i > c && i < rows) xc[(size_t)i * MLD] = -(t0 + t1) * rd;

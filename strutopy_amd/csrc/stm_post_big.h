@@ -49,6 +49,11 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
         relane();
+        if (P.debug_flags & 16) {   // nothing may depend on what an earlier document or kernel left in the LDS
+            __syncthreads();
+            for (int q = lane; q < P.lds_doubles; q += WAVE) big_lds[q] = __builtin_nan("");
+            __syncthreads();
+        }
         const int64_t ticket = P.first + tk;
         const int64_t doc = P.order ? (int64_t)P.order[ticket] : ticket;
         const int64_t p0 = P.indptr[doc];
@@ -130,11 +135,19 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             {
                 double Sp = 0.0, Lp = 0.0;
                 const int kb = fq * kc;
-                for (int kk = 0; kk < kc; ++kk) {
-                    const int k = kb + kk;
-                    const double a = T[(size_t)k * TLD + fr] * sex[k];
-                    Sp += a;              // np.sum(a, 0)
-                    Lp += sth[k] * a;     // theta @ (beta * exp(eta~)), stm.py:1088-1094
+                for (int kk = 0; kk < kc; kk += 8) {   // eight topics' operands in flight; the sums keep their order
+                    double tv[8], ev[8], sv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = kb + kk + u < BT ? kb + kk + u : BT - 1;
+                        tv[u] = T[(size_t)k * TLD + fr]; ev[u] = sex[k]; sv[u] = sth[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double a = (kk + u < kc) ? tv[u] * ev[u] : 0.0;
+                        Sp += a;              // np.sum(a, 0)
+                        Lp += sv[u] * a;      // theta @ (beta * exp(eta~)), stm.py:1088-1094
+                    }
                 }
                 Sp += __shfl_xor(Sp, 16); Sp += __shfl_xor(Sp, 32);
                 Lp += __shfl_xor(Lp, 16); Lp += __shfl_xor(Lp, 32);
@@ -148,25 +161,39 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             }
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[1] += c1 - c0; c0 = c1; }
-            // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
+            // -- 3. scatter phi, rowsum(c'), T <- b (lane = topics k0, k1; four words x two topics in flight)
+            {
+                const bool v0 = k0 < K, v1 = k1 < K;
+                double *tr0 = T + (size_t)k0 * TLD, *tr1 = T + (size_t)k1 * TLD;
+                for (int j0 = 0; j0 < nw; j0 += 4) {
+                    double sqv[4], Sv[4], rv[4], wv[4], a0[4], a1[4];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int k = lane + WAVE * r;
-                if (k < K) {
-                    double *trow = T + (size_t)k * TLD;
-                    for (int j = 0; j < nw; ++j) {
-                        const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                        const double sq = wpar[4 * j], Sj = wpar[4 * j + 1], rj = wpar[4 * j + 2], wj = wpar[4 * j + 3];
-                        const double a = trow[j] * exv[r];
-                        const double num = a * sq;            // b = a*sqrt(c)/S (stm.py:1001)
-                        const double q0 = num * rj;
-                        const double b = fma(fma(-q0, Sj, num), rj, q0);
-                        const double phi = a * wj * sq;       // stm.py:1115-1116
-                        bad |= !(phi >= 0.0);
-                        rowc[r] += b * sq;                    // rowsum(c'), stm.py:1002,1011
-                        trow[j] = b;
-                        unsafeAtomicAdd(bssT + (size_t)idx * K + k, phi);   // stm.py:588
-                        if (dump_phi) P.phi_out[(size_t)k * Nd + t0 + j] = phi;
+                    for (int u = 0; u < 4; ++u) {
+                        const double2 w01 = *reinterpret_cast<const double2 *>(wpar + 4 * (j0 + u));
+                        const double2 w23 = *reinterpret_cast<const double2 *>(wpar + 4 * (j0 + u) + 2);
+                        sqv[u] = w01.x; Sv[u] = w01.y; rv[u] = w23.x; wv[u] = w23.y;
+                        a0[u] = tr0[j0 + u] * exv[0]; a1[u] = tr1[j0 + u] * exv[1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        const bool val = j < nw;      // the words beyond the tile leave zeros in T and add nothing
+                        const int idx = __builtin_amdgcn_readlane(my_idx, j & (TW - 1));
+                        const double n0 = a0[u] * sqv[u], n1 = a1[u] * sqv[u];      // b = a*sqrt(c)/S (stm.py:1001)
+                        const double q0 = n0 * rv[u], q1 = n1 * rv[u];
+                        const double b0 = fma(fma(-q0, Sv[u], n0), rv[u], q0), b1 = fma(fma(-q1, Sv[u], n1), rv[u], q1);
+                        const double ph0 = a0[u] * wv[u] * sqv[u], ph1 = a1[u] * wv[u] * sqv[u];   // stm.py:1115-1116
+                        bad |= val && ((v0 && !(ph0 >= 0.0)) || (v1 && !(ph1 >= 0.0)));
+                        rowc[0] += (val && v0) ? b0 * sqv[u] : 0.0;                 // rowsum(c'), stm.py:1002,1011
+                        rowc[1] += (val && v1) ? b1 * sqv[u] : 0.0;
+                        tr0[j] = (val && v0) ? b0 : 0.0;
+                        tr1[j] = (val && v1) ? b1 : 0.0;
+                        if (val && v0) unsafeAtomicAdd(bssT + (size_t)idx * K + k0, ph0);   // stm.py:588
+                        if (val && v1) unsafeAtomicAdd(bssT + (size_t)idx * K + k1, ph1);
+                        if (dump_phi && val) {
+                            if (v0) P.phi_out[(size_t)k0 * Nd + t0 + j] = ph0;
+                            if (v1) P.phi_out[(size_t)k1 * Nd + t0 + j] = ph1;
+                        }
                     }
                 }
             }
@@ -315,8 +342,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
-                        if (i0 < n && bc < n && i0 >= bc) M[(size_t)i0 * MLD + bc] = old0[r] - a0[r];
-                        if (two && i1 < n && bc < n) M[(size_t)i1 * MLD + bc] = old1[r] - a1[r];
+                        // no masks: rows / columns beyond n are padding nobody reads, and what would land above the
+                        // diagonal (where A lives) goes to the padding column instead
+                        M[(size_t)i0 * MLD + (i0 >= bc ? bc : MLD - 1)] = old0[r] - a0[r];
+                        if (two) M[(size_t)i1 * MLD + bc] = old1[r] - a1[r];
                     }
                 }
                 __syncthreads();
@@ -377,10 +406,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 if (!ok) break;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const int i = lane + WAVE * r;
+                    const int i = lane + WAVE * r, ic = i < MROWS ? i : MROWS - 1;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (i < n && i > J0 + c) M[(size_t)i * MLD + J0 + c] = w[r][c];
+                    for (int c = 0; c < 16; ++c)   // rows on or above the diagonal write to the padding column instead
+                        M[(size_t)ic * MLD + ((i < MROWS && i > J0 + c) ? J0 + c : MLD - 1)] = w[r][c];
                 }
                 __syncthreads();
             }
@@ -484,8 +513,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
                     for (int l = 0; l < 16; l += 2) {
-                        t0 = fma(lv[l], (l >= c && l < i) ? xv[l] : 0.0, t0);
-                        t1 = fma(lv[l + 1], (l + 1 >= c && l + 1 < i) ? xv[l + 1] : 0.0, t1);
+                        // both factors are selected: the row of L runs into columns nobody ever wrote (0 x NaN is NaN)
+                        const bool m0 = l >= c && l < i, m1 = l + 1 >= c && l + 1 < i;
+                        t0 = fma(m0 ? lv[l] : 0.0, m0 ? xv[l] : 0.0, t0);
+                        t1 = fma(m1 ? lv[l + 1] : 0.0, m1 ? xv[l + 1] : 0.0, t1);
                     }
                     // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
                     if (base < n && i > c && i < rows) xc[(size_t)i * MLD] = -(t0 + t1) * rd;

@@ -126,6 +126,26 @@ def test_shapes_at_the_limits(oracle, K, nd_max):
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
 
 
+@pytest.mark.parametrize("K,nd_max", [(17, 70), (50, 90), (64, 90), (100, 60), (128, 40)])
+def test_post_kernels_ignore_stale_lds(oracle, monkeypatch, K, nd_max):
+    """STM_POST_DEBUG=16 fills the post kernel's LDS with NaN before every document: a masked term that multiplies
+    an unwritten cell by zero (instead of selecting it away) turns sigma_ss into NaN."""
+    from strutopy_amd.engine import estep_host
+    monkeypatch.setenv("STM_POST_DEBUG", "16")
+    rng = np.random.default_rng(1000 + K)
+    V, N = 600, 40
+    docs = [np.sort(rng.choice(V, int(rng.integers(1, nd_max + 1)), replace=False)) for _ in range(N)]
+    indptr = np.concatenate([[0], np.cumsum([len(d) for d in docs])]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 6, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    n = K - 1
+    mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
+    siginv, sigent = oracle.preamble(np.eye(n) * 20.0)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} poisoned LDS")
+
+
 def test_k100_two_topics_per_lane(oracle, monkeypatch):
     """BASELINE config 4's K = 100: the two-topics-per-lane solver and post kernel, per-document
     Hessian / Cholesky / nu against the oracle, and the device M-step at n = 99 (resident EM iterations
