@@ -1,11 +1,12 @@
 // stm_post_big.h -- the post-solve step (stm_post.h) for 64 < K <= 128 topics.
 //
-// Same arithmetic, in the same order, as post_kernel (reference src/modules/stm.py:547-588: theta,
-// hessian + make_pd ladder, decompose_hessian, lower_bound, optimize_nu, update_z, accumulation), but
-// a lane owns TWO topics / matrix rows (lane and lane + 64) and everything runs on the VALU: the
-// (K-1)^2 matrix (up to 127 x 127 doubles = 129 KB) takes most of the LDS, so there is one workgroup
-// per CU and no room for the MFMA accumulator sets of the K <= 64 kernel.  This is the coverage path
-// for BASELINE config 4 (K = 100); it is not tuned.
+// Same arithmetic as post_kernel (reference src/modules/stm.py:547-588: theta, hessian + make_pd ladder,
+// decompose_hessian, lower_bound, optimize_nu, update_z, accumulation), but a lane owns TWO topics / matrix
+// rows (lane and lane + 64).  The padded matrix (up to 128 x 129 doubles = 132 KB) takes most of the LDS, so
+// there is one single-wave workgroup per CU -- and that wave has its SIMD's whole 512-entry register file:
+// the b b^T accumulator tiles stay in registers for the whole document, the Cholesky is blocked (matrix-core
+// block column updates, register panels), the inverse and nu = X^T X are the blocked forms of stm_post.h.
+// BASELINE config 4 (K = 100) runs here; see DESIGN.md 4.2b.
 #pragma once
 #include <type_traits>
 #include "stm_post.h"
