@@ -252,6 +252,28 @@ def test_exactly_singular_hessian_after_make_pd(oracle):
     assert np.isfinite(d["sigma_ss"]).all() and np.max(np.abs(d["sigma_ss"])) < 1e7
 
 
+@pytest.mark.parametrize("K", [17, 64, 100, 128])
+def test_pd_ladder_beyond_the_first_rung(oracle, K):
+    """A wide prior (sigma = 1e3 I) leaves the Hessian of random-init documents indefinite: the first Cholesky fails and
+    make_pd (stm.py:964-984, 1019-1020) decides -- the blocked factorisations of both post kernels restart from A in the
+    upper triangle and the ladder's current diagonal."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(10 * K + 1)
+    V, N = 700, 50
+    docs = [np.sort(rng.choice(V, int(rng.integers(1, 120)), replace=False)) for _ in range(N)]
+    indptr = np.concatenate([[0], np.cumsum([len(d) for d in docs])]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 6, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    n = K - 1
+    mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
+    siginv, sigent = oracle.preamble(np.eye(n) * 1e3)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    o = oracle.estep(*args, nthreads=0)
+    assert np.count_nonzero(o["pd_path"]) >= 5
+    _check(estep_host(*args), o, f"K={K} ladder")
+
+
 def test_documents_longer_than_the_lds(oracle):
     """A document whose K x Nd block cannot live in the 160 KB LDS takes the global-slab solver variant;
     shorter ones in the same corpus stay on chip."""
