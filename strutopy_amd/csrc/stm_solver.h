@@ -200,7 +200,7 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
 // the independent pieces of one objective evaluation run on two SIMD slots at once (three barriers
 // per evaluation; everything the solver's control flow sees still passes through wave 0).
 template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1>
-__global__ __launch_bounds__(64 * NW, (KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
+__global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
     constexpr int KMAX = 64 * VPL;
     constexpr int VREG = (KREG > 0) ? WAVE * NW : 0;  // words held in registers
     constexpr int KR = (KREG > 0) ? KREG : 2;
