@@ -198,6 +198,9 @@ static int plan_solver(stm_handle *h) {
     auto per_cu = [&](int nd) -> int {
         const size_t b = ((lds_of(nd) + LDS_STATIC + 511) / 512) * 512;
         if (mode == 2 || b > LDS_PER_CU) return 0;
+        // K > 64: one wave per document and nothing to hide its latencies but other documents -- below four
+        // documents per CU the HBM slab (occupancy bound by registers only) wins (C4: 93 / 25 / 43 -> 54 / 24 / 27 ms)
+        if (h->vpl == 2 && mode == 0 && LDS_PER_CU / b < 4) return 0;
         return (int)std::min<size_t>((size_t)cmax, LDS_PER_CU / b);
     };
     h->groups.clear();

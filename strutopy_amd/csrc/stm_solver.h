@@ -343,13 +343,25 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             const double *row = bT + (size_t)idx * K;
             double *dst = slab + (size_t)vv * KP;
             double colsum = 0.0;
-            for (int k = 0; k < K; ++k) {
+            int k = 0;
+            for (; k + 7 < K; k += 8) {   // eight loads of the lane's row in flight; the column sum keeps its order
+                double b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b[u] = row[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    bad |= !(b[u] >= 0.0);
+                    dst[k + u] = b[u];
+                    colsum += b[u];
+                }
+            }
+            for (; k < K; ++k) {
                 const double b = row[k];
                 bad |= !(b >= 0.0);
                 dst[k] = b;
                 colsum += b;
             }
-            for (int k = K; k < KP; ++k) dst[k] = 0.0;
+            for (k = K; k < KP; ++k) dst[k] = 0.0;
             crow[vv] = c;
             wrow[vv] = c / colsum;
             csum += c;
@@ -452,7 +464,25 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             for (int k = 0; k < KR; ++k)
                 if (k < n) g0_put(k, wave_sum(breg[k] * w0 + g0_slab(k)));
         } else {
-            for (int k = 0; k < n; ++k) g0_put(k, wave_sum(g0_slab(k)));
+            for (int k = 0; k < n; k += 8) {   // eight topics' reductions interleave (each is wave_sum(), unchanged)
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = 0.0;
+                for (int vv = lane; vv < NdL; vv += WAVE) {
+                    const double wq = wrow[vv];
+                    const double *sr = slab + (size_t)vv * KP + k;
+                    double b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) b[u] = sr[k + u < KP ? u : 0];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] += b[u] * wq;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = wave_sum(t[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k + u < n) g0_put(k + u, t[u]);
+            }
         }
 
         const long long t_g3 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
