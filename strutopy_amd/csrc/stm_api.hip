@@ -130,6 +130,7 @@ struct stm_handle {
     void *comm = nullptr;
     int rank = 0, nranks = 1;
     double *d_pack = nullptr;
+    double *d_ascratch = nullptr; size_t ascratch_len = 0;   // post_big_kernel's per-workgroup A
     size_t pack_len = 0;
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -285,7 +286,7 @@ void stm_destroy(stm_handle *h) {
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
     dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu); dfree(h->d_prof);
-    dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack);
+    dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack); dfree(h->d_ascratch);
     if (h->stage) (void)hipHostFree(h->stage);
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -612,6 +613,10 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, 64, lds));
         per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 8)));
         const int64_t grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
+        if (big) {   // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
+            if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * n * n)) return rc;
+            pp.a_scratch = h->d_ascratch;
+        }
         pp.first = 0; pp.count = h->N;
         hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());

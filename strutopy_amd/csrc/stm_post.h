@@ -54,6 +54,7 @@ struct PostParams {
     int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky;
                            // 16 (tests): NaN into the whole LDS allocation before every document
     int lds_doubles;       // size of the dynamic LDS allocation
+    double *a_scratch;     // post_big_kernel: [grid][n][n] A = H + fixes, upper triangle (per-workgroup scratch)
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
     int MLD;               // leading dimension of the LDS matrix (odd, >= n)

@@ -17,9 +17,15 @@ constexpr int BT = 128;   // topics padded to 128
 
 // the matrix is padded to whole 16 x 16 blocks, leading dimension 16 NB + 1 (odd: lane-strided column walks are conflict free)
 inline int post_big_mld(int n) { return 16 * ((n + 15) / 16) + 1; }
+// The LDS matrix is the LOWER block triangle only, row-packed: row i (block b = i / 16) holds its 16 (b + 1) columns
+// plus one padding cell, so rows of a block are an odd stride apart (lane-strided column walks are conflict free).
+// A itself (upper triangle, read only by the block column updates of the Cholesky, make_pd and the dumps) lives in a
+// per-workgroup HBM scratch.  58 KB instead of 101 KB at K = 100: two workgroups per CU.
+__host__ __device__ inline int post_big_row(int i) { const int b = i >> 4, r = i & 15; return 16 * (8 * b * (b + 1) + b) + r * (16 * b + 17); }
 inline size_t post_big_lds_doubles(int n) {
-    const size_t nb = (n + 15) / 16;
-    return ((16 * nb * (16 * nb + 1) + 1) & ~(size_t)1) + (size_t)BT * TLD + 4 * BT + 4 * TW;
+    const int nb = (n + 15) / 16;
+    const size_t tri = (size_t)post_big_row(16 * nb), tile = (size_t)BT * TLD;   // the word tile aliases the matrix (word loop only)
+    return (((tri > tile ? tri : tile) + 1) & ~(size_t)1) + 4 * BT + 4 * TW;
 }
 
 template <int NB>   // NB = ceil((K-1) / 16) block rows: 4 .. 8
@@ -27,10 +33,13 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
     extern __shared__ __attribute__((aligned(16))) double big_lds[];
     int lane = threadIdx.x;
     const int K = P.K, n = P.n;
-    constexpr int MLD = 16 * NB + 1, MROWS = 16 * NB;   // compile-time: tile addresses are immediates
-    double *M = big_lds;                        // [16 NB][MLD]: H, then A (upper) / L, then X = L^-1 (lower)
-    double *T = M + (((size_t)MROWS * MLD + 1) & ~(size_t)1);   // [BT][TLD] word tile, topic-major (16-byte aligned rows)
-    double *sex = T + (size_t)BT * TLD;         // exp(eta~)
+    constexpr int MROWS = 16 * NB;
+    constexpr int MTRI = 16 * (8 * NB * (NB + 1) + NB), REG0 = ((MTRI > BT * TLD ? MTRI : BT * TLD) + 1) & ~1;
+    double *M = big_lds;                        // row-packed lower block triangle (post_big_row): L, then X = L^-1
+    double *T = big_lds;                        // [BT][TLD] word tile, topic-major (16-byte aligned rows); word loop only
+    double *sex = big_lds + REG0;               // exp(eta~)
+    double *Ag = P.a_scratch + (size_t)blockIdx.x * (size_t)n * n;   // A, upper triangle (row-major n x n), HBM scratch
+    auto RS = [](int i) __attribute__((always_inline)) { return post_big_row(i); };
     double *sth = sex + BT;                     // stable_softmax(eta~)
     double *sdv = sth + BT;                     // eta - mu (dense siginv only)
     double *srd = sdv + BT;                     // 1 / diag(L)
@@ -95,7 +104,6 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             sex[k] = exv[r];
             sth[k] = (k < K) ? thsv[r] : 0.0;
         }
-        for (int q = lane; q < MROWS * MLD; q += WAVE) M[q] = 0.0;
         for (int q = lane; q < BT * TLD; q += WAVE) T[q] = 0.0;
         __syncthreads();
 
@@ -226,33 +234,34 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
 
-        {   // b b^T leaves the registers: upper block triangle of M
+        // ---- H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv, formed on the accumulator
+        // tiles and written to the HBM scratch (upper triangle: all that make_pd, the Cholesky and the dumps read);
+        // the diagonal also goes to sdv
+        __syncthreads();
+        srd[lane] = rowc[0]; srd[lane + WAVE] = rowc[1];
+        __syncthreads();
+        {
             int t = 0;
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-                for (int bj = bi; bj < NB; ++bj, ++t)
+                for (int bj = bi; bj < NB; ++bj, ++t) {
+                    const int j = bj * 16 + fr, jc = j < n ? j : n - 1;
+                    const double thj = sth[jc];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
-                        M[(size_t)i * MLD + j] = hacc[t][r];   // padding rows / columns take whatever topic K-1 and the zeros give
+                        const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : n - 1;
+                        const double thi = sth[ic];
+                        double h = hacc[t][r] - Ndoc * (thi * thj);
+                        if (bi == bj) h = (i == j) ? h - srd[ic] + Ndoc * thi : h;
+                        const double sij = (P.siginv_diag && (bi != bj || i != j)) ? 0.0 : S[(size_t)ic * n + jc];
+                        const double v = h + sij;
+                        if (j < n && (bi != bj || (i <= j))) {
+                            Ag[(size_t)i * n + j] = v;
+                            if (bi == bj && i == j) sdv[i] = v;
+                        }
                     }
-        }
-        __syncthreads();
-        // ---- H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv (lane = row)
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = lane + WAVE * r;
-            if (i < n) {
-                double *mi = M + (size_t)i * MLD;
-                const double thi = sth[i];
-                for (int j = i; j < n; ++j) {   // the upper triangle is all that make_pd, the Cholesky and the dumps read
-                    double h = mi[j] - Ndoc * (thi * sth[j]);
-                    if (j == i) h = h - rowc[r] + Ndoc * thi;
-                    const double sij = (P.siginv_diag && j != i) ? 0.0 : S[(size_t)i * n + j];
-                    mi[j] = h + sij;
                 }
-            }
         }
         __syncthreads();
 
@@ -263,19 +272,29 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int i = lane + WAVE * r;
-            diagA[r] = (i < n) ? M[(size_t)i * MLD + i] : 1.0;
+            diagA[r] = (i < n) ? sdv[i] : 1.0;
         }
         auto make_pd = [&]() __attribute__((always_inline)) {  // stm.py:964-984
+            // A comes from the HBM scratch: both rows of the lane and eight columns per round in flight, sums in column order
+            const int i0 = k0 < n ? k0 : n - 1, i1 = k1 < n ? k1 : n - 1;
+            double mag0 = 0.0, mag1 = 0.0;
+            for (int j0 = 0; j0 < n; j0 += 8) {
+                double v0[8], v1[8];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int i = lane + WAVE * r;
-                if (i < n) {
-                    double mag = 0.0;
-                    for (int j = 0; j < n; ++j)
-                        mag += (j == i) ? 0.0 : fabs(j > i ? M[(size_t)i * MLD + j] : M[(size_t)j * MLD + i]);
-                    if (diagA[r] < mag) diagA[r] = mag;
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u < n ? j0 + u : n - 1;
+                    v0[u] = Ag[j > i0 ? (size_t)i0 * n + j : (size_t)j * n + i0];
+                    v1[u] = Ag[j > i1 ? (size_t)i1 * n + j : (size_t)j * n + i1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    mag0 += (j == i0 || j >= n) ? 0.0 : fabs(v0[u]);
+                    mag1 += (j == i1 || j >= n) ? 0.0 : fabs(v1[u]);
                 }
             }
+            if (k0 < n && diagA[0] < mag0) diagA[0] = mag0;
+            if (k1 < n && diagA[1] < mag1) diagA[1] = mag1;
         };
         auto dump = [&](double *base) __attribute__((always_inline)) {
             if (!base) return;
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 const int i = lane + WAVE * r;
                 if (i < n)
                     for (int j = 0; j < n; ++j)
-                        o[(size_t)i * n + j] = (j == i) ? diagA[r] : (j > i ? M[(size_t)i * MLD + j] : M[(size_t)j * MLD + i]);
+                        o[(size_t)i * n + j] = (j == i) ? diagA[r] : (j > i ? Ag[(size_t)i * n + j] : Ag[(size_t)j * n + i]);
             }
         };
         constexpr int nblk = NB;
@@ -311,19 +330,20 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 const int J0 = 16 * p;
                 long long cc0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
                 const int bc = J0 + fr, bcc = bc < n ? bc : nm1;
-                const double *brow = M + (size_t)bcc * MLD;              // row of L_p* for the B operands (L_pk^T)
+                const double *brow = M + RS(bcc);                        // row of L_p* for the B operands (L_pk^T)
+                const double *acol = Ag + (size_t)bcc * n;               // A[i][bc] = A[bc][i], i >= bc: row bc of the upper triangle
 #pragma unroll 1
                 for (int bi = p; bi < nblk; bi += 2) {
                     const bool two = bi + 1 < nblk;
                     const int ar0 = bi * 16 + fr, ar1 = (two ? bi + 1 : bi) * 16 + fr;
-                    const double *arow0 = M + (size_t)(ar0 < n ? ar0 : nm1) * MLD, *arow1 = M + (size_t)(ar1 < n ? ar1 : nm1) * MLD;
+                    const double *arow0 = M + RS(ar0 < n ? ar0 : nm1), *arow1 = M + RS(ar1 < n ? ar1 : nm1);
                     double old0[4], old1[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {   // A[i][j] = M[j][i] (upper), diagonal from sdv
                         const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
                         const int i0c = i0 < n ? i0 : nm1, i1c = i1 < n ? i1 : nm1;
-                        old0[r] = (i0c == bcc) ? sdv[bcc] : brow[i0c];
-                        old1[r] = brow[i1c];
+                        old0[r] = (i0c == bcc) ? sdv[bcc] : acol[i0c >= bcc ? i0c : bcc];
+                        old1[r] = acol[i1c >= bcc ? i1c : bcc];
                     }
                     v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0}, a1 = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
@@ -345,8 +365,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
                         // no masks: rows / columns beyond n are padding nobody reads, and what would land above the
                         // diagonal (where A lives) goes to the padding column instead
-                        M[(size_t)i0 * MLD + (i0 >= bc ? bc : MLD - 1)] = old0[r] - a0[r];
-                        if (two) M[(size_t)i1 * MLD + bc] = old1[r] - a1[r];
+                        M[RS(i0) + (i0 >= bc ? bc : 16 * (bi + 1))] = old0[r] - a0[r];
+                        if (two) M[RS(i1) + bc] = old1[r] - a1[r];
                     }
                 }
                 __syncthreads();
@@ -357,8 +377,9 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int i = lane + WAVE * r, ic = i < n ? i : nm1;
+                    const double *wr = M + RS(ic >= J0 ? ic : J0);   // rows above the panel shadow its first row (never stored)
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) w[r][c] = M[(size_t)ic * MLD + (J0 + c < n ? J0 + c : nm1)];
+                    for (int c = 0; c < 16; ++c) w[r][c] = wr[J0 + c];
                 }
                 // Right-looking inside the panel and free of branches, so that the updates of the later columns fill the
                 // latency of the square root chain: a failed pivot (or a column beyond n) only raises a flag, and whatever
@@ -408,9 +429,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int i = lane + WAVE * r, ic = i < MROWS ? i : MROWS - 1;
+                    double *wr = M + RS(ic);
 #pragma unroll
                     for (int c = 0; c < 16; ++c)   // rows on or above the diagonal write to the padding column instead
-                        M[(size_t)ic * MLD + ((i < MROWS && i > J0 + c) ? J0 + c : MLD - 1)] = w[r][c];
+                        wr[(i < MROWS && i > J0 + c) ? J0 + c : 16 * ((ic >> 4) + 1)] = w[r][c];
                 }
                 __syncthreads();
             }
@@ -437,7 +459,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 const int i = lane + WAVE * r;
                 if (i < n)
                     for (int j = 0; j < n; ++j) {
-                        const double val = (j == i) ? Ldiag[r] : (j < i ? M[(size_t)i * MLD + j] : 0.0);
+                        const double val = (j == i) ? Ldiag[r] : (j < i ? M[RS(i) + j] : 0.0);
                         if (upper) o[(size_t)j * n + i] = val;
                         else o[(size_t)i * n + j] = val;
                     }
@@ -498,17 +520,18 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 const int rows = n - base < 16 ? n - base : 16;    // rows of this lane's block (<= 0: no block)
                 const int rb = base < n ? base : 0;                 // lanes beyond the matrix shadow block 0 (nothing is stored)
                 const int rlast = (rows > 0 ? rows : 16) - 1;
-                double *xc = M + (size_t)rb * MLD + (base < n ? gl : c);
-                if (base < n && c < rows) xc[(size_t)c * MLD] = srd[gl];   // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
+                const int ldb = 16 * (rb >> 4) + 17;                // row stride inside this block of rows
+                double *xc = M + RS(rb) + (base < n ? gl : c);
+                if (base < n && c < rows) xc[(size_t)c * ldb] = srd[gl];   // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
 #pragma unroll 1
                 for (int i = 1; i < 16; ++i) {
                     const int ir = i < rlast ? i : rlast;           // clamped: reads stay inside the matrix
-                    const double *lrow = M + (size_t)(rb + ir) * MLD + rb;
+                    const double *lrow = M + RS(rb) + ir * ldb + rb;
                     double lv[16], xv[16];
 #pragma unroll
                     for (int l = 0; l < 16; ++l) {
                         lv[l] = lrow[l];
-                        xv[l] = xc[(size_t)(l < rlast ? l : rlast) * MLD];
+                        xv[l] = xc[(size_t)(l < rlast ? l : rlast) * ldb];
                     }
                     const double rd = srd[rb + ir];
                     double t0 = 0.0, t1 = 0.0;
@@ -520,7 +543,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         t1 = fma(m1 ? lv[l + 1] : 0.0, m1 ? xv[l + 1] : 0.0, t1);
                     }
                     // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
-                    if (base < n && i > c && i < rows) xc[(size_t)i * MLD] = -(t0 + t1) * rd;
+                    if (base < n && i > c && i < rows) xc[(size_t)i * ldb] = -(t0 + t1) * rd;
                 }
             }
             __syncthreads();
@@ -533,7 +556,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll 1
                 for (int bi = bj + 1; bi < nblk; ++bi) {
                     const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
-                    const double *arow = M + (size_t)arc * MLD;           // row of L_i* / X_ii for the A operands
+                    const double *arow = M + RS(arc);                     // row of L_i* / X_ii for the A operands
                     const int bc = bj * 16 + fr;
                     v4d sacc0 = (v4d){0.0, 0.0, 0.0, 0.0}, sacc1 = (v4d){0.0, 0.0, 0.0, 0.0};
                     int k = bj;
@@ -544,7 +567,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         for (int sk = 0; sk < 8; ++sk) {
                             const int kk = k * 16 + 4 * sk + fq;           // < 16 (nblk - 1) <= n: full blocks only
                             av[sk] = arow[kk];                              // L_ik[fr][4 sk + fq]
-                            bv[sk] = M[(size_t)kk * MLD + bc];              // X_kj[4 sk + fq][fr]
+                            bv[sk] = M[RS(kk) + bc];                        // X_kj[4 sk + fq][fr]
                         }
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) {
@@ -561,7 +584,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         for (int sk = 0; sk < 4; ++sk) {
                             const int kk = k * 16 + 4 * sk + fq;
                             av[sk] = arow[kk];
-                            bv[sk] = M[(size_t)kk * MLD + bc];
+                            bv[sk] = M[RS(kk) + bc];
                         }
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) {
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = bi * 16 + fq + 4 * r;
-                        if (row < n) M[(size_t)row * MLD + bc] = -dacc[r];
+                        if (row < n) M[RS(row) + bc] = -dacc[r];
                     }
                     __syncthreads();
                 }
@@ -623,7 +646,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll 1
                 for (int s4 = bj * 16; s4 < n; s4 += 4) {
                     const int col = s4 + fq, colc = col < n ? col : nm1;
-                    const double *xr = M + (size_t)colc * MLD;
+                    const double *xr = M + RS(colc);
                     double f[8];
 #pragma unroll
                     for (int b = 0; b < 8; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
