@@ -15,17 +15,17 @@ namespace stm {
 
 constexpr int BT = 128;   // topics padded to 128
 
-// the matrix is padded to whole 16 x 16 blocks, leading dimension 16 NB + 1 (odd: lane-strided column walks are conflict free)
-inline int post_big_mld(int n) { return 16 * ((n + 15) / 16) + 1; }
-// The LDS matrix is the LOWER block triangle only, row-packed: row i (block b = i / 16) holds its 16 (b + 1) columns
-// plus one padding cell, so rows of a block are an odd stride apart (lane-strided column walks are conflict free).
-// A itself (upper triangle, read only by the block column updates of the Cholesky, make_pd and the dumps) lives in a
-// per-workgroup HBM scratch.  58 KB instead of 101 KB at K = 100: two workgroups per CU.
-__host__ __device__ inline int post_big_row(int i) { const int b = i >> 4, r = i & 15; return 16 * (8 * b * (b + 1) + b) + r * (16 * b + 17); }
+inline int post_big_mld(int n) { return 16 * ((n + 15) / 16) + 1; }   // (PostParams.MLD is not used by this kernel)
+// The LDS matrix is the LOWER triangle only, row-packed (row i: i + 1 cells).  The blocked code still addresses whole
+// 16 x 16 diagonal blocks: what it reads above the diagonal belongs to the following rows and is selected away, what it
+// would write there goes to a per-lane dump cell behind the matrix.  A itself (upper triangle, read only by the block
+// column updates of the Cholesky, make_pd and the dumps) lives in a per-workgroup HBM scratch.  45 KB instead of 124 KB
+// at K = 100: three workgroups per CU.  Only the n real rows exist: row indices are clamped on reads, masked on writes.
+__host__ __device__ inline int post_big_row(int i) { return (i * (i + 1)) >> 1; }
+__host__ __device__ inline int post_big_tri(int n) { return post_big_row(n) + 16 + WAVE; }   // + slack + dump cells
+__host__ __device__ inline int post_big_reg0(int n) { const int tri = post_big_tri(n), tile = BT * TLD; return ((tri > tile ? tri : tile) + 1) & ~1; }
 inline size_t post_big_lds_doubles(int n) {
-    const int nb = (n + 15) / 16;
-    const size_t tri = (size_t)post_big_row(16 * nb), tile = (size_t)BT * TLD;   // the word tile aliases the matrix (word loop only)
-    return (((tri > tile ? tri : tile) + 1) & ~(size_t)1) + 4 * BT + 4 * TW;
+    return (size_t)post_big_reg0(n) + 4 * BT + 4 * TW;   // the word tile aliases the matrix (word loop only)
 }
 
 template <int NB>   // NB = ceil((K-1) / 16) block rows: 4 .. 8
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
     int lane = threadIdx.x;
     const int K = P.K, n = P.n;
     constexpr int MROWS = 16 * NB;
-    constexpr int MTRI = 16 * (8 * NB * (NB + 1) + NB), REG0 = ((MTRI > BT * TLD ? MTRI : BT * TLD) + 1) & ~1;
-    double *M = big_lds;                        // row-packed lower block triangle (post_big_row): L, then X = L^-1
+    const int MDUMP = post_big_row(n) + 16, REG0 = post_big_reg0(n);
+    double *M = big_lds;                        // row-packed lower triangle (post_big_row): L, then X = L^-1
     double *T = big_lds;                        // [BT][TLD] word tile, topic-major (16-byte aligned rows); word loop only
     double *sex = big_lds + REG0;               // exp(eta~)
     double *Ag = P.a_scratch + (size_t)blockIdx.x * (size_t)n * n;   // A, upper triangle (row-major n x n), HBM scratch
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
                         // no masks: rows / columns beyond n are padding nobody reads, and what would land above the
                         // diagonal (where A lives) goes to the padding column instead
-                        M[RS(i0) + (i0 >= bc ? bc : 16 * (bi + 1))] = old0[r] - a0[r];
-                        if (two) M[RS(i1) + bc] = old1[r] - a1[r];
+                        M[(i0 >= bc && i0 < n) ? RS(i0) + bc : MDUMP + lane] = old0[r] - a0[r];
+                        if (two) M[i1 < n ? RS(i1) + bc : MDUMP + lane] = old1[r] - a1[r];
                     }
                 }
                 __syncthreads();
@@ -428,11 +428,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 if (!ok) break;
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const int i = lane + WAVE * r, ic = i < MROWS ? i : MROWS - 1;
-                    double *wr = M + RS(ic);
+                    const int i = lane + WAVE * r;
 #pragma unroll
                     for (int c = 0; c < 16; ++c)   // rows on or above the diagonal write to the padding column instead
-                        wr[(i < MROWS && i > J0 + c) ? J0 + c : 16 * ((ic >> 4) + 1)] = w[r][c];
+                        M[(i < n && i > J0 + c) ? RS(i) + J0 + c : MDUMP + lane] = w[r][c];
                 }
                 __syncthreads();
             }
@@ -520,18 +519,17 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                 const int rows = n - base < 16 ? n - base : 16;    // rows of this lane's block (<= 0: no block)
                 const int rb = base < n ? base : 0;                 // lanes beyond the matrix shadow block 0 (nothing is stored)
                 const int rlast = (rows > 0 ? rows : 16) - 1;
-                const int ldb = 16 * (rb >> 4) + 17;                // row stride inside this block of rows
-                double *xc = M + RS(rb) + (base < n ? gl : c);
-                if (base < n && c < rows) xc[(size_t)c * ldb] = srd[gl];   // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
+                const int col = base < n ? gl : c;                  // X[rb + l][col] = M[RS(rb + l) + col]
+                if (base < n && c < rows) M[RS(rb + c) + col] = srd[gl];   // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
 #pragma unroll 1
                 for (int i = 1; i < 16; ++i) {
                     const int ir = i < rlast ? i : rlast;           // clamped: reads stay inside the matrix
-                    const double *lrow = M + RS(rb) + ir * ldb + rb;
+                    const double *lrow = M + RS(rb + ir) + rb;
                     double lv[16], xv[16];
 #pragma unroll
                     for (int l = 0; l < 16; ++l) {
                         lv[l] = lrow[l];
-                        xv[l] = xc[(size_t)(l < rlast ? l : rlast) * ldb];
+                        xv[l] = M[RS(rb + (l < rlast ? l : rlast)) + col];
                     }
                     const double rd = srd[rb + ir];
                     double t0 = 0.0, t1 = 0.0;
@@ -543,7 +541,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         t1 = fma(m1 ? lv[l + 1] : 0.0, m1 ? xv[l + 1] : 0.0, t1);
                     }
                     // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
-                    if (base < n && i > c && i < rows) xc[(size_t)i * ldb] = -(t0 + t1) * rd;
+                    if (base < n && i > c && i < rows) M[RS(rb + i) + col] = -(t0 + t1) * rd;
                 }
             }
             __syncthreads();
