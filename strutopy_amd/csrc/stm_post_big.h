@@ -2,11 +2,11 @@
 //
 // Same arithmetic as post_kernel (reference src/modules/stm.py:547-588: theta, hessian + make_pd ladder,
 // decompose_hessian, lower_bound, optimize_nu, update_z, accumulation), but a lane owns TWO topics / matrix
-// rows (lane and lane + 64).  The padded matrix (up to 128 x 129 doubles = 132 KB) takes most of the LDS, so
-// there is one single-wave workgroup per CU -- and that wave has its SIMD's whole 512-entry register file:
-// the b b^T accumulator tiles stay in registers for the whole document, the Cholesky is blocked (matrix-core
-// block column updates, register panels), the inverse and nu = X^T X are the blocked forms of stm_post.h.
-// BASELINE config 4 (K = 100) runs here; see DESIGN.md 4.2b.
+// rows (lane and lane + 64), one wave per workgroup.  That wave has its SIMD's whole 512-entry register file
+// (the b b^T accumulator tiles stay in registers for the whole document), and the LDS holds only the row-packed
+// lower triangle (L, then X = L^-1) so that three workgroups share a CU at K = 100; A (upper triangle) lives in
+// a per-workgroup HBM scratch.  Blocked Cholesky (matrix-core block column updates, register panels), blocked
+// inverse and nu = X^T X as in stm_post.h.  BASELINE config 4 (K = 100) runs here; see DESIGN.md 4.2b.
 #pragma once
 #include <type_traits>
 #include "stm_post.h"
