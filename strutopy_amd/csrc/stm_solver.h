@@ -753,6 +753,21 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             for (int r = 0; r < VPL; ++r)
                 if (lane + WAVE * r < n) sv[lane + WAVE * r] = vec[r];
             STM_WAVE_SYNC_MEM();
+            if constexpr (VPL == 2) {   // H lives in HBM here: both rows of the lane in one loop, sixteen loads in flight
+                const int i0 = lane, i1 = lane + WAVE < n ? lane + WAVE : n - 1;
+                double t0 = 0.0, t1 = 0.0;
+                int j = 0;
+                for (; j + 7 < n; j += 8) {
+                    double h0[8], h1[8], vv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { h0[q] = Hs[(size_t)(j + q) * n + i0]; h1[q] = Hs[(size_t)(j + q) * n + i1]; vv[q] = sv[j + q]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { t0 += h0[q] * vv[q]; t1 += h1[q] * vv[q]; }
+                }
+                for (; j < n; ++j) { const double v = sv[j]; t0 += Hs[(size_t)j * n + i0] * v; t1 += Hs[(size_t)j * n + i1] * v; }
+                out[0] = t0;
+                out[VPL - 1] = (lane + WAVE < n) ? t1 : 0.0;
+            } else
 #pragma unroll
             for (int r = 0; r < VPL; ++r) {
                 const int i = lane + WAVE * r;
@@ -1178,6 +1193,27 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     __syncthreads();   // (u)
                 } else {
                     STM_WAVE_SYNC();
+                    if constexpr (VPL == 2) {   // H in HBM: both columns of the lane, eight rows (sixteen loads) per round
+                        const int j0 = lane, j1 = lane + WAVE < n ? lane + WAVE : n - 1;
+                        const bool v1 = lane + WAVE < n;
+                        const double s0 = s[0], s1 = s[VPL - 1], w0 = w[0], w1 = w[VPL - 1];
+                        for (int i = 0; i < n; i += 8) {
+                            double h0[8], h1[8], si[8], wi[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int ic = i + q < n ? i + q : n - 1;
+                                h0[q] = H_ident ? (ic == j0 ? 1.0 : 0.0) : Hs[(size_t)ic * n + j0];
+                                h1[q] = H_ident ? (ic == j1 ? 1.0 : 0.0) : Hs[(size_t)ic * n + j1];
+                                si[q] = sv[ic]; wi[q] = sw[ic];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (i + q < n) {   // uniform
+                                    Hs[(size_t)(i + q) * n + j0] = h0[q] - rhok * (si[q] * w0 + wi[q] * s0) + cc * (si[q] * s0);
+                                    if (v1) Hs[(size_t)(i + q) * n + j1] = h1[q] - rhok * (si[q] * w1 + wi[q] * s1) + cc * (si[q] * s1);
+                                }
+                        }
+                    } else
 #pragma unroll
                     for (int r = 0; r < VPL; ++r) {
                         const int j = lane + WAVE * r;
