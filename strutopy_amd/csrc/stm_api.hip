@@ -572,6 +572,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
             const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl);
             const unsigned bdim = gr.global ? 64u : 64u * (unsigned)h->nw;
             sp.ld = gr.ld;
+            sp.lds_doubles = (int)(gr.lds_bytes / sizeof(double));
             int64_t step = h->chunk;
             if (gr.global)
                 step = std::min<int64_t>(step, std::max<int64_t>(1, (int64_t)(h->slab_beta_len / ((size_t)(sp.KP + 2) * (size_t)std::max(gr.ld, 1)))));

@@ -55,6 +55,7 @@ struct SolverParams {
     const int32_t *order;   // optional processing order (nullable)
     int32_t *status, *nit, *nfev, *njev;
     int32_t *err_flag;
+    int lds_doubles;        // dynamic LDS of this launch, in doubles (debug bit3 poisons it)
     int debug_flags;        // bit0: skip the BFGS loop (bring-up aid); bit1: no line-search cuts, bit2: no reuse of DCSRCH's first
                             // evaluation by wolfe2 (every evaluation scipy makes is made: A/B check of the shortcuts)
     long long *prof;        // optional [N][40] shader-clock totals per document: [0] init, [1] evaluations, [2] state machine,
@@ -233,6 +234,11 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     {
         const int64_t ticket = P.first + blockIdx.x;
         if (ticket >= P.N) return;
+        if (P.debug_flags & 8) {   // tests: nothing may depend on what an earlier workgroup left in the LDS
+            for (int q = threadIdx.x; q < P.lds_doubles; q += WAVE * NW) dyn_lds[q] = __builtin_nan("");
+            for (int q = threadIdx.x; q < KMAX + 1; q += WAVE * NW) { sv[q] = __builtin_nan(""); sw[q] = __builtin_nan(""); se[q] = __builtin_nan(""); }
+            __syncthreads();
+        }
         const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
         const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
         const int64_t p0 = scalar_load(P.indptr + doc);

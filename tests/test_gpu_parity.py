@@ -128,10 +128,12 @@ def test_shapes_at_the_limits(oracle, K, nd_max):
 
 @pytest.mark.parametrize("K,nd_max", [(17, 70), (50, 90), (64, 90), (100, 60), (128, 40)])
 def test_post_kernels_ignore_stale_lds(oracle, monkeypatch, K, nd_max):
-    """STM_POST_DEBUG=16 fills the post kernel's LDS with NaN before every document: a masked term that multiplies
+    """STM_POST_DEBUG=16 fills the post kernel's LDS with NaN before every document (STM_DEBUG_FLAGS=8: the solver's, per
+    workgroup): a masked term that multiplies
     an unwritten cell by zero (instead of selecting it away) turns sigma_ss into NaN."""
     from strutopy_amd.engine import estep_host
     monkeypatch.setenv("STM_POST_DEBUG", "16")
+    monkeypatch.setenv("STM_DEBUG_FLAGS", "8")     # the solver's LDS too (per workgroup)
     rng = np.random.default_rng(1000 + K)
     V, N = 600, 40
     docs = [np.sort(rng.choice(V, int(rng.integers(1, nd_max + 1)), replace=False)) for _ in range(N)]
