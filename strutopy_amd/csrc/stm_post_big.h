@@ -116,28 +116,47 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         v4d hacc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) hacc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        // the word ids / counts of a tile are fetched two tiles ahead, its beta rows one tile ahead (32 loads in flight
+        // across the previous tile's sums, scatter and matrix-core steps)
+        auto load_ids = [&](int t0, int &idx, double &c) __attribute__((always_inline)) {
+            const bool in = t0 + lane < Nd && lane < TW;
+            idx = in ? P.indices[p0 + t0 + lane] : 0;
+            c = in ? P.counts[p0 + t0 + lane] : 0.0;
+        };
+        double gv[2][TW];
+        auto load_rows = [&](int idx_lane) __attribute__((always_inline)) {   // words beyond the document carry id 0, lanes beyond K read topic 0
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int idx = __builtin_amdgcn_readlane(idx_lane, j);
+                    gv[r][j] = bT[(size_t)idx * K + (lane + WAVE * r < K ? lane + WAVE * r : 0)];
+                }
+        };
+        int my_idx, idx1;
+        double my_c, c1n;
+        load_ids(0, my_idx, my_c);
+        load_ids(TW, idx1, c1n);
+        constexpr bool PREFETCH = NB < 8;   // at NB = 8 the 36 accumulator tiles leave no room for a tile of rows in flight
+        if (PREFETCH) load_rows(my_idx);
         for (int t0 = 0; t0 < Nd; t0 += TW) {
             relane();
             const int nw = Nd - t0 < TW ? Nd - t0 : TW;
-            const int my_idx = (lane < nw) ? P.indices[p0 + t0 + lane] : 0;
-            const double my_c = (lane < nw) ? P.counts[p0 + t0 + lane] : 0.0;
             long long c0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-            // -- 1. gather: coalesced beta rows, transposed into T[topic][word]
-            // a row set's 16 loads first (words beyond the document carry id 0, lanes beyond K read topic 0), then its stores
+            if (!PREFETCH) load_rows(my_idx);
+            // -- 1. the tile's beta rows (issued one tile ago), transposed into T[topic][word]
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int k = lane + WAVE * r;
-                double gv[TW];
-#pragma unroll
-                for (int j = 0; j < TW; ++j) {
-                    const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                    gv[j] = bT[(size_t)idx * K + (k < K ? k : 0)];
-                }
                 double2 *row = reinterpret_cast<double2 *>(T + (size_t)k * TLD);
 #pragma unroll
                 for (int j = 0; j < TW; j += 2)
-                    row[j >> 1] = make_double2((k < K && j < nw) ? gv[j] : 0.0, (k < K && j + 1 < nw) ? gv[j + 1] : 0.0);
+                    row[j >> 1] = make_double2((k < K && j < nw) ? gv[r][j] : 0.0, (k < K && j + 1 < nw) ? gv[r][j + 1] : 0.0);
             }
+            int idx2;
+            double c2n;
+            if (PREFETCH && t0 + TW < Nd) load_rows(idx1);
+            load_ids(t0 + 2 * TW, idx2, c2n);
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[0] += c1 - c0; c0 = c1; }
             // -- 2. per-word sums, lane = (word fr, topic quarter fq)
@@ -227,6 +246,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             }
             __syncthreads();
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[3] += c1 - c0; c0 = c1; }
+            my_idx = idx1; my_c = c1n; idx1 = idx2; c1n = c2n;
         }
         if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
         if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
