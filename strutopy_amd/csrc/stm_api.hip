@@ -625,6 +625,7 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((n * n + 63) / 64), dim3(256), 0, h->stream,
                        h->d_sigma_part, h->nrep, n * n, h->d_sigma_ss);
+    if (K > stm::PT) hipLaunchKernelGGL(stm::mirror_blocks_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, h->d_sigma_ss, n);
     hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));

@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         const int i = b * 16 + fq + 4 * r, j = rj;
                         if (i < n && j < n) {
                             unsafeAtomicAdd(sig_acc + (size_t)i * n + j, acc[b][r]);
-                            if (b != bj) unsafeAtomicAdd(sig_acc + (size_t)j * n + i, acc[b][r]);
+                            // blocks below the block diagonal are mirrored once, after the replicas are summed (mirror_blocks_kernel)
                             if (nu_doc) {
                                 nu_doc[(size_t)i * n + j] = acc[b][r];
                                 nu_doc[(size_t)j * n + i] = acc[b][r];
@@ -700,6 +700,14 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         }
         __syncthreads();
     }
+}
+
+// sigma_ss[i][j] = sigma_ss[j][i] for the 16 x 16 blocks below the block diagonal (post_big_kernel adds nu's upper block triangle only)
+__global__ void mirror_blocks_kernel(double *a, int n) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n * n) return;
+    const int i = q / n, j = q % n;
+    if ((i >> 4) > (j >> 4)) a[q] = a[(size_t)j * n + i];
 }
 
 }  // namespace stm
