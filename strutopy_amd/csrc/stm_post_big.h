@@ -345,6 +345,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             // every pivot that passes lies in (32 eps, 1] x its diagonal entry (up to rounding): the range test of
             // sqrt_and_rsqrt can be made on the diagonal, once
             const bool fast_sqrt = !wave_any((k0 < n && !(diagA[0] > 1e-260 && diagA[0] < 1e270)) || (k1 < n && !(diagA[1] > 1e-260 && diagA[1] < 1e270)));
+            // A pivot never exceeds its diagonal entry (the products subtracted from it are squares, in floating point too),
+            // so a diagonal entry <= 0 (or NaN) fails some pivot test for certain: the outcome of this attempt is known
+            // without factorising (at random init most K = 100 documents leave the first rung this way).
+            if (wave_any((k0 < n && !(diagA[0] > 0.0)) || (k1 < n && !(diagA[1] > 0.0)))) ok = false;
 #pragma unroll 1
             for (int p = 0; p < nblk && ok; ++p) {
                 const int J0 = 16 * p;
