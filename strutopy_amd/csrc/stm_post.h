@@ -381,6 +381,9 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         // (L[j+1][j] by v_readlane), and the serial per-column tail (pivot broadcast, sqrt, reciprocal,
         // LDS hand-off) is paid once per pair.
         auto cholesky = [&]() -> bool {
+            // a pivot never exceeds its diagonal entry (what is subtracted from it are squares, in floating point too): an
+            // entry <= 0 (or NaN) fails some pivot test for certain, and the attempt is decided without factorising
+            if (wave_any(isn && !(diagA > 0.0))) return false;
             bool ok = true;
             int j = 0;
             for (; j + 1 < n; j += 2) {
