@@ -261,6 +261,9 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         srd[lane] = rowc[0]; srd[lane + WAVE] = rowc[1];
         __syncthreads();
         {
+            double sdg[NB];   // siginv's diagonal at column 16 b + fr, all blocks' loads in flight at once
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const int j = b * 16 + fr < n ? b * 16 + fr : n - 1; sdg[b] = S[(size_t)j * n + j]; }
             int t = 0;
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi)
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         const double thi = sth[ic];
                         double h = hacc[t][r] - Ndoc * (thi * thj);
                         if (bi == bj) h = (i == j) ? h - srd[ic] + Ndoc * thi : h;
-                        const double sij = (P.siginv_diag && (bi != bj || i != j)) ? 0.0 : S[(size_t)ic * n + jc];
+                        const double sij = (bi == bj && i == j) ? sdg[bj] : (P.siginv_diag ? 0.0 : S[(size_t)ic * n + jc]);
                         const double v = h + sij;
                         if (j < n && (bi != bj || (i <= j))) {
                             Ag[(size_t)i * n + j] = v;
