@@ -23,6 +23,7 @@
 // and is accumulated ON THE MATRIX CORES ACROSS ALL DOCUMENTS of the workgroup
 // (sigma_ss = sum_d R_d R_d^T); one atomic flush per workgroup at the end of the launch.
 #pragma once
+#include <type_traits>
 #include "stm_wave.h"
 
 namespace stm {
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
                 // zeros and get zeros back.  b = a * (sqrt(c) / S) serves both the Hessian (stm.py:1001, which
                 // divides a * sqrt(c) by S: <= 1.5 ulp apart) and phi = b * sqrt(c) (stm.py:1115-1116, this order);
                 // rowsum(c') of stm.py:1002,1011 is the row sum of that same product.
-                for (int j0 = 0; j0 < nw; j0 += 4) {
+                auto round4 = [&](int j0, auto fullc) __attribute__((always_inline)) {
                     double2 *tp2 = reinterpret_cast<double2 *>(trow + j0);
                     const double2 ta = tp2[0], tb = tp2[1];
                     const double2 *wp2 = reinterpret_cast<const double2 *>(wpar + 2 * j0);
@@ -267,12 +268,18 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int j = j0 + u;
-                        if (j < nw) {   // uniform
+                        if (decltype(fullc)::value || j < nw) {   // uniform
                             const int idx = __builtin_amdgcn_readlane(my_idx, j);
                             if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, ph[u]);  // stm.py:588
                             if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = ph[u];
                         }
                     }
+                };
+                if (nw == TW) {   // a full tile: the four rounds in one straight line, their LDS reads in flight together
+#pragma unroll
+                    for (int j0 = 0; j0 < TW; j0 += 4) round4(j0, std::true_type{});
+                } else {
+                    for (int j0 = 0; j0 < nw; j0 += 4) round4(j0, std::false_type{});
                 }
             }
             STM_POST_SYNC();
