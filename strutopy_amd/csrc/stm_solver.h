@@ -222,6 +222,9 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
     double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
     double *crow = slab + (size_t)KP * ld;  // counts of the slab words
+    // the HBM slab is topic-major (slab[k][word]: a wave's read of one topic for 64 words is one coalesced run), the LDS
+    // slab word-major (slab[word][KP]: a lane streams its own row with ds_read_b128)
+    auto SI = [&](int vv, int k) __attribute__((always_inline)) -> size_t { return GLOBAL_SLAB ? (size_t)k * ld + vv : (size_t)vv * KP + k; };
     double *wrow = crow + ld;               // counts / colsum(beta_d)
     // BFGS inverse-Hessian estimate (n x n): in LDS behind the slab for the two-wave form (its slab is
     // small), in a private global slab otherwise
@@ -347,7 +350,6 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             const int idx = P.indices[p0 + VREG + vv];
             const double c = P.counts[p0 + VREG + vv];
             const double *row = bT + (size_t)idx * K;
-            double *dst = slab + (size_t)vv * KP;
             double colsum = 0.0;
             int k = 0;
             for (; k + 7 < K; k += 8) {   // eight loads of the lane's row in flight; the column sum keeps its order
@@ -357,17 +359,17 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     bad |= !(b[u] >= 0.0);
-                    dst[k + u] = b[u];
+                    slab[SI(vv, k + u)] = b[u];
                     colsum += b[u];
                 }
             }
             for (; k < K; ++k) {
                 const double b = row[k];
                 bad |= !(b >= 0.0);
-                dst[k] = b;
+                slab[SI(vv, k)] = b;
                 colsum += b;
             }
-            for (k = K; k < KP; ++k) dst[k] = 0.0;
+            for (k = K; k < KP; ++k) slab[SI(vv, k)] = 0.0;
             crow[vv] = c;
             wrow[vv] = c / colsum;
             csum += c;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
         auto g0_slab = [&](int k) __attribute__((always_inline)) -> double {
             double t = 0.0;
-            for (int vv = lane; vv < NdL; vv += WAVE) t += slab[(size_t)vv * KP + k] * wrow[vv];
+            for (int vv = lane; vv < NdL; vv += WAVE) t += slab[SI(vv, k)] * wrow[vv];
             return t;
         };
         auto g0_put = [&](int k, double t) __attribute__((always_inline)) {
@@ -438,12 +440,12 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             // so that the KREG reduction chains interleave; three forms of the slab term: none (this wave owns no slab
             // words), one word per lane (at most 64 slab words), the general strided loop
             const double wl = (NdL > 0 && NdL <= WAVE && lane < NdL) ? wrow[lane] : 0.0;
-            const double *srow = slab + (size_t)((NdL <= WAVE && lane < NdL) ? lane : 0) * KP;
+            const int srow_w = (NdL <= WAVE && lane < NdL) ? lane : 0;
             auto chains = [&](auto mode) __attribute__((always_inline)) {
 #pragma unroll
                 for (int k = 0; k < KR; ++k) {
                     double v = breg[k] * w0;
-                    if (decltype(mode)::value == 1) v = v + ((lane < NdL) ? srow[k] * wl : 0.0);
+                    if (decltype(mode)::value == 1) v = v + ((lane < NdL) ? slab[SI(srow_w, k)] * wl : 0.0);
                     if (decltype(mode)::value == 2) v = v + g0_slab(k);
                     v += dpp_move<DPP_XOR1>(v);
                     v += dpp_move<DPP_XOR2>(v);
@@ -476,10 +478,9 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 for (int u = 0; u < 8; ++u) t[u] = 0.0;
                 for (int vv = lane; vv < NdL; vv += WAVE) {
                     const double wq = wrow[vv];
-                    const double *sr = slab + (size_t)vv * KP + k;
                     double b[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) b[u] = sr[k + u < KP ? u : 0];
+                    for (int u = 0; u < 8; ++u) b[u] = slab[SI(vv, k + u < KP ? k + u : k)];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) t[u] += b[u] * wq;
                 }
@@ -554,9 +555,27 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 const int va = vb + lane, vc = va + WAVE;
                 const bool two = vb + WAVE < NdL;  // uniform
                 const int ia = va < NdL ? va : NdL - 1, ic = vc < NdL ? vc : NdL - 1;
+                double a0 = 0.0, a1 = 0.0;
+                if constexpr (GLOBAL_SLAB) {   // topic-major HBM slab: the same sums in the same order, coalesced loads
+                    const double *pa = slab + ia, *pc = slab + ic;
+                    double c0s = 0.0, c1s = 0.0;
+#pragma unroll 4
+                    for (int kk = 0; kk < kp2; ++kk) {
+                        const double2 e = se2[kk];
+                        const double bax = pa[(size_t)(2 * kk) * ld], bay = pa[(size_t)(2 * kk + 1) * ld];
+                        const double bcx = pc[(size_t)(2 * kk) * ld], bcy = pc[(size_t)(2 * kk + 1) * ld];
+                        a0 = fma(e.x, bax, a0);
+                        a1 = fma(e.y, bay, a1);
+                        c0s = fma(e.x, bcx, c0s);
+                        c1s = fma(e.y, bcy, c1s);
+                    }
+                    const double la = m + log_pos(a0 + a1), lc = m + log_pos(c0s + c1s);
+                    part += (va < NdL) ? crow[ia] * la : 0.0;
+                    part += (two && vc < NdL) ? crow[ic] * lc : 0.0;
+                    continue;
+                }
                 const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
                 const double2 *rc = reinterpret_cast<const double2 *>(slab + (size_t)ic * KP);
-                double a0 = 0.0, a1 = 0.0;
                 if (two) {
                     double c0s = 0.0, c1s = 0.0;
 #pragma unroll 5
