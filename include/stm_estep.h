@@ -112,10 +112,14 @@ int stm_estep_host(const stm_estep_args *args, int device_ordinal);
 
 /* ---- M-step on the device (stm.py:622-747, next-row f-1) -------------- */
 /* prevalence covariates X [N][p] as used by update_mu (stm.py:661-671, already
- * one-hot encoded by the host when the reference would encode them) */
+ * one-hot encoded by the host when the reference would encode them); any p (the moment region grows) */
 int stm_put_covariates(stm_handle *h, const double *X, int32_t p);
-/* local (this shard's) regression moments for update_mu (stm.py:678-706):
- * out = [ n_docs | sum_x (p) | sum_eta (K-1) | XtX (p*p) | Xt_eta (p*(K-1)) ] */
+/* local (this shard's) moments for update_mu (stm.py:678-706) and update_sigma (stm.py:723), written into the
+ * moment region of the packed sufficient-statistic buffer and, when out != NULL, copied to the host:
+ *   [ n_docs | sum_x (p) | sum_eta (K-1) | XtX (p*p) | Xt_eta (p*(K-1)) | eta^T eta ((K-1)^2) ]
+ * (p = 0 without covariates: the CTM branch).  With gamma from the centred moments,
+ * (eta - X gamma^T)^T (eta - X gamma^T) = eta^T eta - gamma Xt_eta - (gamma Xt_eta)^T + gamma XtX gamma^T,
+ * so document shards exchange everything the M-step needs in ONE all-reduce. */
 int stm_mstep_moments(stm_handle *h, double *out, int64_t out_len);
 /* mu_d = x_d @ gamma^T (stm.py:706; gamma [(K-1)][p]) or, when gamma == NULL,
  * mu_d = mean_eta (CTM branch, stm.py:651; mean_eta [(K-1)]) */
@@ -141,9 +145,11 @@ int stm_eval_heldout(stm_handle *h, int64_t N, const int64_t *indptr, const int3
 int stm_comm_unique_id(void *out128);
 int stm_comm_init(stm_handle *h, const void *uid128, int rank, int nranks);
 /* sum over ranks, in place on the device, of the packed buffer
- * [ bound | sigma_ss | moments (extra_len doubles, host in/out) | beta_ss ] */
-int stm_allreduce_suffstats(stm_handle *h, double *bound_total, double *extra, int64_t extra_len);
-/* sum over ranks of a small host vector through the device (covariance) */
+ * [ bound | sigma_ss | moments (as left by stm_mstep_moments) | beta_ss ];
+ * the first moments_len doubles of the reduced moment region are copied to `moments` (nullable when 0).
+ * Without a communicator (one GPU) nothing is reduced and the local values are returned. */
+int stm_allreduce_suffstats(stm_handle *h, double *bound_total, double *moments, int64_t moments_len);
+/* sum over ranks of a host vector of any length through its own device buffer (the covariance fallback) */
 int stm_allreduce_small(stm_handle *h, double *buf, int64_t len);
 
 /* ---- timing / profiling ---------------------------------------------- */

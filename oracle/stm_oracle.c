@@ -821,13 +821,22 @@ int stm_oracle_estep(const stm_oracle_args *a, int nthreads) {
     (void)nthreads;
 #endif
     if (nt < 1) nt = 1;
-    /* per-thread partial sufficient statistics, reduced in thread order afterwards */
-    double **bss = (double **)calloc((size_t)nt, sizeof(double *));
+    /* sigma_ss: per-thread partials ((K-1)^2 each), reduced in thread order afterwards.
+     * beta_ss: ONE word-major accumulator [A][V][K] shared by the threads (a document touches Nd runs of K
+     * doubles; atomic adds when nt > 1), transposed into beta_ss at the end -- per-thread K x V replicas cost
+     * more than the E-step itself once there are a few dozen threads.  beta is gathered from a word-major copy
+     * for the same reason (stm.py:614-617 gathers K strided columns per document). */
     double **sss = (double **)calloc((size_t)nt, sizeof(double *));
-    bss[0] = a->beta_ss; sss[0] = a->sigma_ss;
-    for (int t = 1; t < nt; ++t) {
-        bss[t] = (double *)calloc(KV, sizeof(double));
-        sss[t] = (double *)calloc((size_t)n * n, sizeof(double));
+    sss[0] = a->sigma_ss;
+    for (int t = 1; t < nt; ++t) sss[t] = (double *)calloc((size_t)n * n, sizeof(double));
+    double *bssT = (double *)calloc(KV, sizeof(double));
+    double *betaT = (double *)malloc(sizeof(double) * KV);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+    for (int64_t av = 0; av < (int64_t)A * V; ++av) {
+        const size_t lev = (size_t)(av / V), w = (size_t)(av % V);
+        for (int k = 0; k < K; ++k) betaT[(size_t)av * K + k] = a->beta[lev * K * V + (size_t)k * V + w];
     }
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nt)
@@ -853,15 +862,17 @@ int stm_oracle_estep(const stm_oracle_args *a, int nthreads) {
             const int64_t p0 = a->indptr[i];
             const int Nd = (int)(a->indptr[i + 1] - p0);
             const int asp = a->aspect ? a->aspect[i] : 0;
-            const double *beta_a = a->beta + (size_t)asp * K * V;
+            const double *betaT_a = betaT + (size_t)asp * K * V;
             /* get_beta: beta[:, idx] (stm.py:614-617) + assert beta >= 0 (stm.py:534) */
             int bad = 0;
-            for (int k = 0; k < K; ++k)
-                for (int v = 0; v < Nd; ++v) {
-                    double bv = beta_a[(size_t)k * V + a->indices[p0 + v]];
+            for (int v = 0; v < Nd; ++v) {
+                const double *row = betaT_a + (size_t)a->indices[p0 + v] * K;
+                for (int k = 0; k < K; ++k) {
+                    double bv = row[k];
                     if (!(bv >= 0)) bad = 1;
                     betad[(size_t)k * Nd + v] = bv;
                 }
+            }
             if (bad) {
 #ifdef _OPENMP
 #pragma omp critical
@@ -904,26 +915,38 @@ int stm_oracle_estep(const stm_oracle_args *a, int nthreads) {
             if (a->phi_last && i == N - 1) memcpy(a->phi_last, phi, sizeof(double) * (size_t)K * Nd);
             double *ss = sss[tid];
             for (size_t q = 0; q < (size_t)n * n; ++q) ss[q] += nu[q]; /* stm.py:582 */
-            double *bs = bss[tid] + (size_t)asp * K * V;                /* stm.py:584-588 */
-            for (int k = 0; k < K; ++k)
-                for (int v = 0; v < Nd; ++v) bs[(size_t)k * V + a->indices[p0 + v]] += phi[(size_t)k * Nd + v];
+            double *bs = bssT + (size_t)asp * K * V;                    /* stm.py:584-588 */
+            for (int v = 0; v < Nd; ++v) {
+                double *row = bs + (size_t)a->indices[p0 + v] * K;
+                if (nt > 1) {
+                    for (int k = 0; k < K; ++k) {
+#ifdef _OPENMP
+#pragma omp atomic update
+#endif
+                        row[k] += phi[(size_t)k * Nd + v];
+                    }
+                } else {
+                    for (int k = 0; k < K; ++k) row[k] += phi[(size_t)k * Nd + v];
+                }
+            }
         }
         free(betad); free(work); free(wK); free(phi); free(Hm);
     }
-    /* reduce the per-thread partials in thread order (parallel over the entries) */
+    /* word-major accumulator -> beta_ss [A][K][V] */
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(nt) schedule(static)
 #endif
-    for (int64_t q = 0; q < (int64_t)KV; ++q) {
-        double t_ = a->beta_ss[q];
-        for (int t = 1; t < nt; ++t) t_ += bss[t][q];
-        a->beta_ss[q] = t_;
+    for (int64_t ak = 0; ak < (int64_t)A * K; ++ak) {
+        const size_t lev = (size_t)(ak / K), k = (size_t)(ak % K);
+        for (int w = 0; w < V; ++w) a->beta_ss[(size_t)ak * V + w] = bssT[(lev * V + (size_t)w) * K + k];
     }
+    free(bssT); free(betaT);
+    /* reduce the per-thread sigma_ss partials in thread order */
     for (int t = 1; t < nt; ++t) {
         for (size_t q = 0; q < (size_t)n * n; ++q) a->sigma_ss[q] += sss[t][q];
-        free(bss[t]); free(sss[t]);
+        free(sss[t]);
     }
-    free(bss); free(sss);
+    free(sss);
     double tot = 0.0;
     for (int64_t i = 0; i < N; ++i) tot += bound[i]; /* stm.py:592 */
     if (a->bound_total) *a->bound_total = tot;

@@ -14,6 +14,7 @@
   100k / 1M document configurations.
 """
 from dataclasses import dataclass
+from itertools import chain
 
 import numpy as np
 
@@ -57,25 +58,26 @@ class PackedCorpus:
 
 
 def pack_bow(documents, V=None):
-    """list[list[(word_id, count)]] -> PackedCorpus.  Mirrors np.array(doc) of stm.py:522."""
+    """list[list[(word_id, count)]] -> PackedCorpus, once (the reference rebuilds np.array(documents[i]) for
+    every document in every EM iteration, stm.py:522-533).  One pass of C-level iterators over the nested
+    sequences -- no per-document Python statement or NumPy call."""
     if isinstance(documents, PackedCorpus):
         return documents
     N = len(documents)
-    lens = np.fromiter((len(d) for d in documents), dtype=np.int64, count=N)
+    lens = np.fromiter(map(len, documents), dtype=np.int64, count=N)
     if N and lens.min() < 1:
         raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
     indptr = np.zeros(N + 1, dtype=np.int64)
     np.cumsum(lens, out=indptr[1:])
     nnz = int(indptr[-1])
-    indices = np.empty(nnz, dtype=np.int32)
-    counts = np.empty(nnz, dtype=np.float64)
-    pos = 0
-    for d in documents:
-        arr = np.asarray(d)
-        k = arr.shape[0]
-        indices[pos:pos + k] = arr[:, 0]
-        counts[pos:pos + k] = arr[:, 1]
-        pos += k
+    try:
+        flat = np.fromiter(chain.from_iterable(chain.from_iterable(documents)), dtype=np.float64, count=2 * nnz)
+    except ValueError as e:   # an entry that is not a (word_id, count) pair
+        raise IndexError(f"documents must hold (word_id, count) pairs (stm.py:522-526): {e}") from None
+    indices = flat[0::2].astype(np.int32)
+    counts = np.ascontiguousarray(flat[1::2])
+    if nnz and (indices.min() < 0 or np.any(indices != flat[0::2])):
+        raise IndexError("word ids must be non-negative integers below 2^31")
     vmax = int(indices.max()) + 1 if nnz else 0
     if V is None:
         V = vmax
@@ -87,28 +89,38 @@ def pack_bow(documents, V=None):
 def read_mm(path):
     """MatrixMarket coordinate file (documents x terms, 1-based, as gensim's MmCorpus writes the
     reference's src/artifacts/wiki_data/BoW_corpus.mm) -> PackedCorpus, without going through Python
-    lists of tuples (the reference rebuilds np.array(documents[i]) per document per iteration, stm.py:522)."""
-    with open(path) as fh:
+    lists of tuples (the reference rebuilds np.array(documents[i]) per document per iteration, stm.py:522).
+    Entries of one document keep their file order when the file is already grouped by document (gensim writes
+    it that way); otherwise they are grouped stably."""
+    with open(path, "rb") as fh:
         head = fh.readline()
-        if not head.startswith("%%MatrixMarket matrix coordinate"):
+        if not head.startswith(b"%%MatrixMarket matrix coordinate"):
             raise ValueError("not a MatrixMarket coordinate file")
         line = fh.readline()
-        while line.startswith("%"):
+        while line.startswith(b"%"):
             line = fh.readline()
         n_docs, n_terms, nnz = (int(t) for t in line.split())
-        data = np.loadtxt(fh, ndmin=2)
-    if data.shape[0] != nnz:
-        raise ValueError(f"expected {nnz} entries, found {data.shape[0]}")
+        try:   # the C tokenizer of pandas: ~20x np.loadtxt
+            import pandas as pd
+            data = pd.read_csv(fh, sep=r"\s+", header=None, comment="%", dtype=np.float64, engine="c").to_numpy()
+        except ImportError:
+            data = np.loadtxt(fh, ndmin=2)
+    if data.shape[0] != nnz or (nnz and data.shape[1] != 3):
+        raise ValueError(f"expected {nnz} entries of (doc, term, value), found an array of shape {data.shape}")
     doc = data[:, 0].astype(np.int64) - 1
     term = data[:, 1].astype(np.int64) - 1
-    order = np.lexsort((term, doc))
-    doc, term, val = doc[order], term[order], data[order, 2]
+    val = data[:, 2]
+    if nnz and (doc.min() < 0 or doc.max() >= n_docs or term.min() < 0 or term.max() >= n_terms):
+        raise ValueError("entry outside the declared matrix shape")
+    if nnz and np.any(np.diff(doc) < 0):
+        order = np.argsort(doc, kind="stable")
+        doc, term, val = doc[order], term[order], val[order]
     lens = np.bincount(doc, minlength=n_docs)
     if n_docs and lens.min() < 1:
         raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
     indptr = np.zeros(n_docs + 1, dtype=np.int64)
     np.cumsum(lens, out=indptr[1:])
-    return PackedCorpus(indptr, term.astype(np.int32), val.astype(np.float64), int(n_terms))
+    return PackedCorpus(indptr, term.astype(np.int32), np.ascontiguousarray(val, dtype=np.float64), int(n_terms))
 
 
 @dataclass

@@ -22,7 +22,10 @@ namespace {
 thread_local std::string g_err;
 
 // doubles reserved in the packed all-reduce buffer for the M-step moments
-constexpr size_t STM_EXTRA_MAX = 4096;
+// [ n_docs | sum_x (p) | sum_eta (n) | XtX (p*p) | Xt_eta (p*n) | eta^T eta (n*n) ]: sized for p <= 8 covariate
+// columns when the model is set up, grown by stm_put_covariates when X is wider
+constexpr size_t moments_len(int p, int n) { return 1 + (size_t)p + n + (size_t)p * p + (size_t)p * n + (size_t)n * n; }
+constexpr size_t round64(size_t x) { return (x + 63) / 64 * 64; }
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -129,7 +132,8 @@ struct stm_handle {
     // comm
     void *comm = nullptr;
     int rank = 0, nranks = 1;
-    double *d_pack = nullptr;
+    double *d_pack = nullptr, *d_extra = nullptr, *d_small = nullptr;
+    size_t extra_cap = 0, small_len = 0;
     double *d_ascratch = nullptr; size_t ascratch_len = 0;   // post_big_kernel's per-workgroup A
     size_t pack_len = 0;
     // timing
@@ -286,7 +290,7 @@ void stm_destroy(stm_handle *h) {
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
     dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu); dfree(h->d_prof);
-    dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack); dfree(h->d_ascratch);
+    dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack); dfree(h->d_ascratch); dfree(h->d_small);
     if (h->stage) (void)hipHostFree(h->stage);
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -363,12 +367,17 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     h->K = K; h->n = K - 1;
     const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
     if (int rc = dalloc(&h->d_betaT, KV + 64)) return rc;   // + 64: the solver reads KREG <= 64 doubles from a row start, masked beyond K
-    // one packed buffer [ scalars(8) | sigma_ss | extra | beta_ss ] so a single all-reduce covers it
-    h->pack_len = 8 + n * n + STM_EXTRA_MAX + KV;
+    // one packed buffer [ scalars(8) | sigma_ss | moments | beta_ss ] so a single all-reduce covers it
+    h->extra_cap = round64(moments_len(8, h->n));
+    h->pack_len = 8 + n * n + h->extra_cap + KV;
     if (int rc = dalloc(&h->d_pack, h->pack_len)) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_pack, 0, sizeof(double) * h->pack_len, h->stream));
     h->d_scal = h->d_pack;
     h->d_sigma_ss = h->d_pack + 8;
-    h->d_beta_ssT = h->d_pack + 8 + n * n + STM_EXTRA_MAX;
+    h->d_extra = h->d_pack + 8 + n * n;
+    h->d_beta_ssT = h->d_extra + h->extra_cap;
+    h->p = 0;
+    dfree(h->d_X);
     if (int rc = dalloc(&h->d_tmpKV, KV)) return rc;
     if (int rc = dalloc(&h->d_eta, N * n)) return rc;
     if (int rc = dalloc(&h->d_mu, N * n)) return rc;

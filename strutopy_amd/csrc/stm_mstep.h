@@ -68,7 +68,7 @@ __global__ void set_mu_kernel(const double *X, const double *gamma, const double
     mu[q] = t;
 }
 
-// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j]; n <= 128.
+// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j] (mu == nullptr: eta^T eta); n <= 128.
 // 256 threads: thread (ty, tx) = (t / 64, t % 64) owns column j = tx + 64 blockIdx.y of rows
 // i = 64 blockIdx.z + ty, ty+4, ...  (grid y = z = ceil(n / 64))
 __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, const double *mu, int64_t N,
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, cons
         const int cnt = (int)((d1 - base) < TD ? (d1 - base) : TD);
         for (int q = threadIdx.x; q < TD * 128; q += 256) {
             const int dd = q >> 7, i = q & 127;
-            diff[dd][i] = (dd < cnt && i < n) ? eta[(base + dd) * n + i] - mu[(base + dd) * n + i] : 0.0;
+            diff[dd][i] = (dd < cnt && i < n) ? (mu ? eta[(base + dd) * n + i] - mu[(base + dd) * n + i] : eta[(base + dd) * n + i]) : 0.0;
         }
         __syncthreads();
         for (int dd = 0; dd < cnt; ++dd) {

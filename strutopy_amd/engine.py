@@ -160,8 +160,9 @@ class HipEstepEngine:
         self.p = X.shape[1]
 
     def moments(self, p):
+        """[N | sum_x | sum_eta | XtX | Xt_eta | eta^T eta] of this shard; also left in the packed device buffer."""
         n = self.K - 1
-        L = 1 + p + n + p * p + p * n
+        L = 1 + p + n + p * p + p * n + n * n
         out = np.zeros(L)
         check(self._L.stm_mstep_moments(self._h, dptr(out), L))
         return out
@@ -203,12 +204,13 @@ class HipEstepEngine:
         buf = C.create_string_buffer(uid, 128)
         check(self._L.stm_comm_init(self._h, buf, int(rank), int(nranks)))
 
-    def allreduce_suffstats(self, extra):
-        """All-reduce [bound | sigma_ss | extra | beta_ss] over the ranks; returns (bound, extra)."""
-        extra = f64(extra).copy()
+    def allreduce_suffstats(self, moments):
+        """All-reduce the packed [bound | sigma_ss | moments | beta_ss] in place on the device; returns
+        (bound, reduced moments).  `moments` is what moments() returned (its values already sit in the buffer)."""
+        out = np.zeros(len(np.asarray(moments).ravel()))
         tot = C.c_double(0.0)
-        check(self._L.stm_allreduce_suffstats(self._h, C.byref(tot), dptr(extra), len(extra)))
-        return tot.value, extra
+        check(self._L.stm_allreduce_suffstats(self._h, C.byref(tot), dptr(out) if len(out) else None, len(out)))
+        return tot.value, out
 
     def allreduce_small(self, buf):
         buf = f64(buf).copy()

@@ -34,8 +34,12 @@ def _default_engine(device):
     return HipEstepEngine(device)
 
 
-def encode_covariates(X):
-    """The covariate preparation of update_mu (stm.py:656-671): 2-D, one-hot unless already 0/1."""
+def encode_covariates(X, comm=None):
+    """The covariate preparation of update_mu (stm.py:656-671): 2-D, one-hot unless already 0/1.
+
+    With a multi-rank `comm`, X is this rank's document shard: whether the columns count as "already 0/1"
+    and the category list of every column are agreed on over ALL shards first, so every rank builds the
+    same columns in the same order (what the reference's OneHotEncoder sees is the whole corpus)."""
     if X is None:
         return None
     try:
@@ -47,13 +51,18 @@ def encode_covariates(X):
     prev_cov = np.array(X)[:, None]
     if prev_cov.ndim > 2:
         prev_cov = np.squeeze(prev_cov, axis=1)
-    if not np.array_equal(prev_cov, prev_cov.astype(bool)):
+    is_bool = bool(np.array_equal(prev_cov, prev_cov.astype(bool)))
+    cats = [np.unique(prev_cov[:, j]) for j in range(prev_cov.shape[1])]
+    if comm is not None and comm.size > 1:
+        infos = comm.allgather((prev_cov.shape[1], is_bool, cats))
+        if len({i[0] for i in infos}) != 1:
+            raise ValueError("X has a different number of columns on different ranks")
+        is_bool = all(i[1] for i in infos)
+        cats = [np.unique(np.concatenate([i[2][j] for i in infos])) for j in range(prev_cov.shape[1])]
+    if not is_bool:
         # sklearn OneHotEncoder semantics: per column, sorted categories -> indicator columns
-        cols = []
-        for j in range(prev_cov.shape[1]):
-            cats = np.unique(prev_cov[:, j])
-            cols.append((prev_cov[:, j][:, None] == cats[None, :]).astype(np.float64))
-        prev_cov = np.concatenate(cols, axis=1)
+        prev_cov = np.concatenate([(prev_cov[:, j][:, None] == cats[j][None, :]).astype(np.float64)
+                                   for j in range(prev_cov.shape[1])], axis=1)
     return np.ascontiguousarray(prev_cov, dtype=np.float64)
 
 
@@ -115,10 +124,14 @@ class STM:
                                 aspect=self._aspect, A=self._levels)
         self._engine.set_topics(self.K)
         self.comm.attach(self._engine)
-        self._Xenc = encode_covariates(X) if model_type == "STM" else None
+        self._Xenc = encode_covariates(X, self.comm) if model_type == "STM" else None
         if self._Xenc is not None and len(self._Xenc) != self.N:
             raise ValueError("X must have one row per document")
         self._cov_on_device = False
+        self._phi = None
+        self._phi_stale = False
+        self.cov_exchange = "moments"    # "exact": always take the second (K-1)^2 all-reduce of the local covariance
+        self.cov_exchanges = []          # per resident iteration: which form was used
         # which side holds the fresh copy of each array ("host" | "device" | "both")
         self._fresh = dict(beta="host", eta="host", mu="host", theta="host")
         self.init_params()
@@ -144,6 +157,21 @@ class STM:
     beta = property(lambda s: s._host_value("beta"), lambda s, v: s._set_host("beta", v))
     eta = property(lambda s: s._host_value("eta"), lambda s, v: s._set_host("eta", v))
     mu = property(lambda s: s._host_value("mu"), lambda s, v: s._set_host("mu", v))
+
+    @property
+    def phi(self):
+        """stm.py:1116 leaves the last document's phi in self.phi; fetched from the device on first use."""
+        if self._phi_stale:
+            try:
+                self._phi = self._engine.get_phi_last()
+            except Exception:
+                self._phi = None
+            self._phi_stale = False
+        return self._phi
+
+    @phi.setter
+    def phi(self, v):
+        self._phi, self._phi_stale = v, False
 
     @property
     def theta(self):
@@ -211,6 +239,7 @@ class STM:
         bound_local = self._engine.estep(self.siginv, float(self.sigmaentropy))
         self._fresh["eta"] = "device"
         self._fresh["theta"] = "device"
+        self._phi_stale = True
         self._estep_seconds = time.time() - t0
         return bound_local
 
@@ -223,10 +252,6 @@ class STM:
             bound = bound_local
         beta_ss = self._engine.get_beta_ss()
         sigma_ss = self._engine.get_sigma_ss()
-        try:
-            self.phi = self._engine.get_phi_last()  # stm.py:1116 leaves the last document's phi
-        except Exception:
-            self.phi = None
         self.bound = bound
         self.last_bounds.append(self.bound)
         logger.info(f"Lower Bound: {self.bound}")
@@ -302,25 +327,44 @@ class STM:
             raise NotImplementedError("lda_beta=False (mnreg, reference stm.py:749-853) is out of scope")
 
     # ------------------------------------------------------------------ device-resident EM iteration
-    def _em_iteration_resident(self):
-        """E-step + one all-reduce + M-step with eta / mu / beta / theta kept in HBM.
+    def _covariance_from_moments(self, ete, n_tot, se, XtX=None, Xte=None):
+        """(eta - mu)^T (eta - mu) (stm.py:723) from the all-reduced moments, with mu_d = x_d gamma^T (stm.py:706)
+        or the column mean (CTM, stm.py:651).  Returns (covariance, smallest diag(cov) / diag(eta^T eta))."""
+        if XtX is None:
+            m = se / n_tot
+            cov = ete - n_tot * np.outer(m, m)
+        else:
+            C = self.gamma
+            M = C @ Xte
+            Q = C @ XtX @ C.T
+            cov = ete - M - M.T + 0.5 * (Q + Q.T)
+        d = np.diag(ete)
+        ratio = float(np.min(np.diag(cov)[d > 0] / d[d > 0])) if np.any(d > 0) else 1.0
+        return cov, ratio
 
-        Same arithmetic as E_step() + M_step(); the regression and covariance are formed from
-        moments so that document shards only exchange O(K^2 + K V) numbers.
+    def _em_iteration_resident(self):
+        """E-step + ONE all-reduce + M-step with eta / mu / beta / theta kept in HBM.
+
+        Same arithmetic as E_step() + M_step(); the regression and the covariance are formed from
+        moments so that document shards only exchange O(K^2 + K V) numbers, once.
         """
         eng = self._engine
         n = self.K - 1
         t0 = time.time()
-        bound_local = self._estep_device()
-        t1 = time.time()
-        use_reg = self.model == "STM"
         if self.model not in ("STM", "CTM"):
             raise ValueError("model_type must be 'STM' or 'CTM'")
-        if use_reg and self.mode not in ("ols", "ridge"):
+        use_reg = self.model == "STM"
+        if use_reg and self.mode == "lasso":
             raise NotImplementedError("mode='lasso' needs the full eta on the host: use E_step()/M_step()")
+        if use_reg and self.mode not in ("ols", "ridge") and not getattr(self, "_mode_notice", False):
+            # the reference's own fallback (stm.py:696-700)
+            print("Need to specify the estimation mode of prevalence covariate coefficients. Uses default 'ols'.")
+            self._mode_notice = True
         if use_reg and not self._cov_on_device:
-            eng.put_covariates(self._Xenc)
+            eng.put_covariates(self._Xenc)      # before the E-step: a wide X re-allocates the packed buffer
             self._cov_on_device = True
+        bound_local = self._estep_device()
+        t1 = time.time()
         p = self._Xenc.shape[1] if use_reg else 0
         mom = eng.moments(p)
         bound, mom = self.comm.allreduce_suffstats(eng, mom)
@@ -331,9 +375,11 @@ class STM:
         Ntot = mom[0]
         sx = mom[1:1 + p]
         se = mom[1 + p:1 + p + n]
+        o = 1 + p + n
+        ete = mom[o + p * p + p * n:].reshape(n, n)
         if use_reg:
-            XtX = mom[1 + p + n:1 + p + n + p * p].reshape(p, p)
-            Xte = mom[1 + p + n + p * p:].reshape(p, n)
+            XtX = mom[o:o + p * p].reshape(p, p)
+            Xte = mom[o + p * p:o + p * p + p * n].reshape(p, n)
             xbar, ebar = sx / Ntot, se / Ntot
             Sxx = XtX - Ntot * np.outer(xbar, xbar)
             Sxe = Xte - Ntot * np.outer(xbar, ebar)
@@ -343,10 +389,18 @@ class STM:
                 coef = np.linalg.pinv(Sxx, rcond=1e-12, hermitian=True) @ Sxe  # minimum-norm OLS
             self.gamma = coef.T                                              # (K-1) x p, stm.py:703
             eng.set_mu_regression(self.gamma)
+            cov, ratio = self._covariance_from_moments(ete, Ntot, se, XtX, Xte)
         else:
             eng.set_mu_constant(se / Ntot)                                   # stm.py:651
+            cov, ratio = self._covariance_from_moments(ete, Ntot, se)
         self._fresh["mu"] = "device"
-        cov = self.comm.allreduce_small(eng, eng.covariance())               # stm.py:723
+        # the expansion loses -log10(ratio) digits to cancellation; every rank sees the same reduced moments,
+        # so every rank takes the same branch
+        if self.cov_exchange == "exact" or not np.isfinite(ratio) or ratio < 1e-4:
+            cov = self.comm.allreduce_small(eng, eng.covariance())           # stm.py:723, second all-reduce
+            self.cov_exchanges.append("exact")
+        else:
+            self.cov_exchanges.append("moments")
         sigma_ss = eng.get_sigma_ss()
         self._finish_sigma(cov, sigma_ss, self.sigma_prior)
         if not self.LDAbeta:

@@ -65,10 +65,11 @@ class OracleEngine:
 
     def moments(self, p):
         n = self.K - 1
+        ete = (self.eta.T @ self.eta).ravel()
         if p == 0:
-            return np.concatenate([[float(self.N)], self.eta.sum(0)])
+            return np.concatenate([[float(self.N)], self.eta.sum(0), ete])
         X = self.X
-        return np.concatenate([[float(self.N)], X.sum(0), self.eta.sum(0), (X.T @ X).ravel(), (X.T @ self.eta).ravel()])
+        return np.concatenate([[float(self.N)], X.sum(0), self.eta.sum(0), (X.T @ X).ravel(), (X.T @ self.eta).ravel(), ete])
 
     def set_mu_regression(self, gamma): self.mu = self.X @ np.asarray(gamma).T
     def set_mu_constant(self, mean_eta): self.mu = np.repeat(np.asarray(mean_eta)[None, :], self.N, axis=0)

@@ -1,7 +1,7 @@
-"""N>1 path on CPU: two gloo ranks, each owning a contiguous document shard, exchanging the packed
-sufficient statistics once per EM iteration (strutopy_amd.dist) -- must reproduce the single-process
-fit.  OracleEngine stands in for the HIP engine (test hook); the exchange / M-step-from-moments logic
-is the code under test."""
+"""N>1 path on CPU: two ranks (torch.distributed/gloo, and the product's own stdlib TCP group), each owning a
+contiguous document shard, exchanging the packed sufficient statistics once per EM iteration
+(strutopy_amd.dist) -- must reproduce the single-process fit.  OracleEngine stands in for the HIP
+engine (test hook); the exchange / M-step-from-moments logic is the code under test."""
 import os
 import socket
 import sys
@@ -20,9 +20,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, model_type, iters, q):
+def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="binary"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       OMP_NUM_THREADS="2")
+    os.environ.pop("STM_RDZV_PORT", None)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle_engine import OracleEngine
@@ -31,23 +32,43 @@ def _worker(rank, world, port, case, model_type, iters, q):
     from strutopy_amd.stm import STM
     g = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
     full = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
-    sdist.init_from_env("gloo")
-    comm = sdist.GlooComm()
+    if group == "gloo":
+        import datetime
+
+        import torch.distributed as tdist
+        tdist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+        comm = sdist.GlooComm()
+    else:   # the product's host group: stdlib sockets, rendezvous file keyed by MASTER_PORT
+        comm = sdist.HostComm(sdist.init_from_env(timeout=120))
     lo, hi = sdist.shard_bounds(full.indptr, world)[rank]
-    m = STM(documents=full.slice(lo, hi), dictionary=None, content=False, K=int(g["K"]), X=g["X"][lo:hi, 0],
+    X = _covariate(g, xkind)
+    m = STM(documents=full.slice(lo, hi), dictionary=None, content=False, K=int(g["K"]), X=X[lo:hi],
             kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
             init_type="random", model_type=model_type, comm=comm, engine=OracleEngine(nthreads=2))
     assert m.N_total == full.N
     m.expectation_maximization(saving=False)
     q.put((rank, lo, hi, list(m.last_bounds), m.sigma.copy(), m.beta.copy(), m.mu.copy(), m.eta.copy(),
            getattr(m, "gamma", None)))
-    import torch.distributed as tdist
-    tdist.barrier()
-    tdist.destroy_process_group()
+    comm.barrier()
+    if group == "gloo":
+        tdist.destroy_process_group()
+    else:
+        comm.group.close()
 
 
-@pytest.mark.parametrize("case,model_type", [("c1_k10", "STM"), ("toy_ctm", "CTM")])
-def test_two_rank_fit_equals_single_process(case, model_type):
+def _covariate(g, xkind):
+    """binary: the golden's own 0/1 column.  sorted3: a three-level covariate SORTED along the corpus, so each
+    contiguous shard sees a different subset of the levels (one shard even sees only {0, 1}, which on its own
+    would count as "already 0/1", stm.py:665)."""
+    if xkind == "binary":
+        return g["X"][:, 0]
+    N = len(g["indptr"]) - 1
+    return np.minimum(np.arange(N) * 3 // max(N - 40, 1), 2)
+
+
+@pytest.mark.parametrize("case,model_type,group,xkind", [("c1_k10", "STM", "gloo", "binary"), ("toy_ctm", "CTM", "gloo", "binary"),
+                                                         ("c1_k10", "STM", "tcp", "binary"), ("c1_k10", "STM", "tcp", "sorted3")])
+def test_two_rank_fit_equals_single_process(case, model_type, group, xkind):
     import torch.multiprocessing as mp
     from _oracle_engine import OracleEngine
     from strutopy_amd.corpus import PackedCorpus
@@ -57,7 +78,7 @@ def test_two_rank_fit_equals_single_process(case, model_type):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, model_type, iters, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, model_type, iters, q, group, xkind)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
@@ -65,7 +86,7 @@ def test_two_rank_fit_equals_single_process(case, model_type):
         p.join(timeout=60)
         assert p.exitcode == 0
     full = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
-    ref = STM(documents=full, dictionary=None, content=False, K=int(g["K"]), X=g["X"][:, 0],
+    ref = STM(documents=full, dictionary=None, content=False, K=int(g["K"]), X=_covariate(g, xkind),
               kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
               init_type="random", model_type=model_type, engine=OracleEngine())
     ref.expectation_maximization(saving=False)
@@ -80,5 +101,51 @@ def test_two_rank_fit_equals_single_process(case, model_type):
     # both ranks finish the (replicated) M-step with identical global parameters
     assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])
     # and the trace still matches the reference's golden trace
-    for it in range(iters):
+    for it in range(iters if xkind == "binary" else 1):
         assert res[0][3][it] == pytest.approx(float(g[f"it{it}_bound"]), rel=1e-8)
+
+
+def _tcp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", STM_RDZV_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from strutopy_amd import dist as sdist
+    g = sdist.init_from_env(timeout=60)
+    out = dict(rank=g.rank, size=g.size)
+    out["gather"] = g.allgather(("r", rank))
+    out["sum"] = g.allreduce(np.arange(5.0) * (rank + 1))
+    out["max"] = g.allreduce(np.array([float(rank), -float(rank)]), op="max")
+    out["bcast"] = g.broadcast(b"x" * 128 if rank == 1 else None, src=1)
+    g.barrier()
+    q.put(out)
+    g.barrier()
+    g.close()
+
+
+def test_tcp_group_collectives_three_ranks():
+    """strutopy_amd.dist.TcpGroup (stdlib sockets only): what ships the ncclUniqueId and the few host scalars."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(3)), key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for o in res:
+        assert o["size"] == 3 and o["gather"] == [("r", 0), ("r", 1), ("r", 2)]
+        assert np.array_equal(o["sum"], np.arange(5.0) * 6) and np.array_equal(o["max"], [2.0, 0.0])
+        assert o["bcast"] == b"x" * 128
+
+
+def test_product_comm_path_is_torch_free():
+    """north_star: host code is Python + ctypes, no PyTorch -- importing the package and building the product's
+    host group must not import torch (GlooGroup, the CPU test rig, is the only torch user)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import strutopy_amd, strutopy_amd.dist as d; "
+            "g = d.init_from_env(); c = d.RcclComm(g); assert c.size == 1; "
+            "assert 'torch' not in sys.modules, 'torch was imported'" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
+    subprocess.run([sys.executable, "-c", code], check=True, env=env)

@@ -1,0 +1,316 @@
+"""Round-2 parity cases on a real MI355X (all through the C-ABI): the device M-step for per-level beta, later EM
+iterations at K=50 (teacher-forced against the reference), BASELINE config 4's per-GPU share, the multi-rank
+paths (host reduction between two processes on one GPU, bench.py's own launcher, a one-rank RCCL communicator at
+K=100), and the ctypes stub of INTEGRATION.md executed against an object with the reference's attributes."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, reference_beta0
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def _corpus(g):
+    from strutopy_amd.corpus import PackedCorpus
+    return PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+
+
+# ------------------------------------------------------------------ C5: content covariate, device M-step for A > 1
+def test_resident_em_with_content_levels_against_reference():
+    """content=True + kappa_interactions=True, A=2: the resident loop runs beta_normalise_topics_kernel (the
+    reference's np.sum(beta_ss, axis=1) over TOPICS for a 3-D beta_ss, stm.py:741) -- against the reference's
+    own two EM iterations (tests/golden/content_a2.npz)."""
+    from strutopy_amd import STM
+    g = load_golden("content_a2")
+    out = {}
+    for resident in (True, False):
+        m = STM(documents=_corpus(g), dictionary=None, content=True, K=int(g["K"]), X=g["X"][:, 0], kappa_interactions=True,
+                A=int(g["A"]), beta_index=g["aspect"], max_em_iter=2, sigma_prior=0, convergence_threshold=1e-12,
+                init_type="random", model_type="STM")
+        assert m.beta.shape == (2, int(g["K"]), int(g["V"])) and np.array_equal(m.beta, g["beta0"])
+        m.expectation_maximization(saving=False, resident=resident)
+        assert m.last_bounds[0] == pytest.approx(float(g["it0_bound"]), rel=1e-10)
+        assert m.last_bounds[1] == pytest.approx(float(g["it1_bound"]), rel=1e-8)
+        assert np.allclose(m.beta, g["it1_beta_out"], rtol=1e-6, atol=1e-12)
+        assert np.allclose(m.sigma, g["it1_sigma_out"], rtol=1e-6, atol=1e-9)
+        used = g["it1_beta_out"].sum(axis=1) > 0
+        assert np.allclose(m.beta.sum(axis=1)[used], 1.0, atol=1e-9)
+        out[resident] = (m.beta.copy(), m.sigma.copy(), m.gamma.copy())
+        m.close()
+    for a, b in zip(out[True], out[False]):
+        assert np.allclose(a, b, rtol=1e-7, atol=1e-11)
+
+
+def test_content_levels_full_iteration_at_k50(oracle):
+    """One full resident EM iteration at C5's shape per GPU share scaled down (K=50, V=10k, A=2, 3000 documents):
+    device M-step vs the NumPy statement of stm.py:741-745 on the device's own beta_ss."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(3000, 10_000, 50, n_words=150, seed=5)
+    aspect = np.random.default_rng(1).integers(0, 2, size=3000).astype(np.int32)
+    m = STM(documents=syn.corpus, dictionary=None, content=True, K=50, X=syn.X, kappa_interactions=True, A=2,
+            beta_index=aspect, max_em_iter=1, sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    beta0, c = m.beta.copy(), syn.corpus
+    m._em_iteration_resident()
+    beta_ss = m._engine.get_beta_ss()
+    o = oracle.estep(c.indptr, c.indices, c.counts, beta0, np.zeros((c.N, 49)), np.zeros((c.N, 49)), m.siginv,
+                     float(m.sigmaentropy), aspect=aspect, nthreads=0)
+    assert m.bound == pytest.approx(o["bound"], rel=1e-10)
+    assert _rel(beta_ss, o["beta_ss"]) <= 1e-7
+    rs = beta_ss.sum(axis=1)[:, None]                                  # axis=1 of (A, K, V): over topics
+    want = np.divide(beta_ss, rs, out=np.zeros_like(beta_ss), where=rs != 0)
+    assert np.allclose(m.beta, want, rtol=1e-12, atol=0)
+    m.close()
+
+
+# ------------------------------------------------------------------ K=50, later EM iterations, teacher-forced
+@pytest.mark.parametrize("flags", ["0", "6"])
+def test_k50_later_iterations_teacher_forced(oracle, monkeypatch, flags):
+    """tests/golden/k50_late.npz: the reference's EM iterations 3, 4, 5 and 8 at K=50 / V=10k (2000 documents) with the
+    complete input state of each E-step.  From iteration 4 on about half of the documents take BFGS steps that move; the
+    HIP solver must follow scipy exactly there.  STM_DEBUG_FLAGS=6 disables the outcome-preserving line-search cuts:
+    both builds must agree with the reference AND with each other (the cuts change nothing)."""
+    from strutopy_amd.engine import estep_host
+    monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
+    g = load_golden("k50_late")
+    for it in g["kept"]:
+        p = f"it{int(it)}_"
+        args = (g["indptr"], g["indices"], g["counts"], g[p + "beta_in"], g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                float(g[p + "sigmaentropy"]))
+        d = estep_host(*args)
+        for k in ("status", "nit", "pd_path"):
+            assert np.array_equal(d[k], g[p + k]), f"it{it}: {k} differs from the reference in {np.sum(d[k] != g[p + k])} documents"
+        assert np.max(np.abs(d["eta"] - g[p + "eta"])) <= 1e-7
+        assert np.max(np.abs(d["bound_doc"] - g[p + "bound_doc"]) / np.abs(g[p + "bound_doc"])) <= 1e-8
+        assert abs(d["bound"] - float(g[p + "bound"])) <= 1e-10 * abs(float(g[p + "bound"]))
+        assert _rel(d["sigma_ss"], g[p + "sigma_ss"]) <= 1e-8
+        assert _rel(d["beta_ss"].sum(axis=1), g[p + "beta_ss_rowsum"]) <= 1e-9
+        assert _rel(d["beta_ss"].sum(axis=0), g[p + "beta_ss_colsum"]) <= 1e-9
+        if int(it) >= 4:
+            assert np.mean(g[p + "nit"] > 0) > 0.2          # the regime this case exists for
+        if flags == "0":   # and the oracle, evaluation by evaluation (nfev is informational between GPU and oracle)
+            o = oracle.estep(*args, nthreads=0)
+            assert np.array_equal(o["status"], g[p + "status"]) and np.array_equal(o["nit"], g[p + "nit"])
+            assert np.max(np.abs(d["eta"] - o["eta"])) <= 1e-7
+
+
+# ------------------------------------------------------------------ C4's per-GPU share
+def test_config4_share_invariants_and_oracle_sample(oracle):
+    """BASELINE configs[3] per GPU: 125k documents, V=50k, K=100 (beta = 40 MB, beyond the L2): size-independent
+    invariants on everything, the oracle on a 500-document sample."""
+    from strutopy_amd.corpus import synthetic_corpus
+    from strutopy_amd.engine import HipEstepEngine
+    syn = synthetic_corpus(125_000, 50_000, 100, n_words=150, seed=12345)
+    c, K, n = syn.corpus, 100, 99
+    beta = reference_beta0(K, c.V)
+    e = HipEstepEngine(0)
+    e.set_corpus(c.indptr, c.indices, c.counts, c.V)
+    e.set_topics(K)
+    e.put_beta(beta)
+    siginv, sigent = np.eye(n) / 20.0, float(n * 0.5 * np.log(20.0))
+    bound = e.estep(siginv, sigent)
+    eta, theta, beta_ss, sigma_ss, bd, diag = e.get_eta(), e.get_theta(), e.get_beta_ss(), e.get_sigma_ss(), e.get_bound_docs(), e.get_diagnostics()
+    assert _rel(beta_ss.sum(axis=0), c.word_counts()) <= 1e-11           # phi columns sum to the word counts
+    assert abs(beta_ss.sum() - c.counts.sum()) <= 1e-11 * c.counts.sum() and beta_ss.min() >= 0
+    assert np.allclose(theta.sum(axis=1), 1.0, atol=1e-12) and theta.min() > 0
+    assert np.allclose(theta[:, :-1] / theta[:, -1:], np.exp(eta), rtol=1e-12)
+    assert np.allclose(sigma_ss, sigma_ss.T, rtol=1e-12) and np.linalg.eigvalsh(sigma_ss).min() > 0
+    assert np.isfinite(bd).all() and bound == pytest.approx(bd.sum(), rel=1e-12)
+    assert set(np.unique(diag["status"])) <= {0, 2} and set(np.unique(diag["pd_path"])) <= {0, 1, 2}
+    S = 500
+    sub = c.slice(0, S)
+    z = np.zeros((S, n))
+    o = oracle.estep(sub.indptr, sub.indices, sub.counts, beta, z, z, siginv, sigent, nthreads=0)
+    for k in ("status", "nit", "pd_path"):
+        assert np.array_equal(diag[k][:S], o[k]), k
+    assert np.max(np.abs(eta[:S] - o["eta"])) <= 1e-7
+    assert np.max(np.abs(bd[:S] - o["bound_doc"]) / np.abs(o["bound_doc"])) <= 1e-8
+    # second E-step from the moved state (eta of the first, same beta): the trajectories of later iterations
+    b2 = e.estep(siginv, sigent)
+    o2 = oracle.estep(sub.indptr, sub.indices, sub.counts, beta, z, eta[:S], siginv, sigent, nthreads=0)
+    d2 = e.get_diagnostics()
+    assert np.array_equal(d2["status"][:S], o2["status"]) and np.array_equal(d2["nit"][:S], o2["nit"])
+    assert np.max(np.abs(e.get_eta()[:S] - o2["eta"])) <= 1e-7 and np.isfinite(b2)
+    e.close()
+
+
+# ------------------------------------------------------------------ multi-rank paths
+def test_k100_resident_em_through_a_one_rank_rccl_communicator():
+    """at K >= 66 the (K-1)^2 covariance did not fit the old fixed-size all-reduce region.
+    K=100 with a real (one-rank) RCCL communicator, both covariance forms, and a covariate wide enough (41 one-hot
+    columns) that the moment region of the packed buffer has to grow -- against the host-NumPy M-step."""
+    from strutopy_amd import STM, dist as sdist
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(400, 3000, 100, n_words=120, seed=8)
+    Xcat = np.random.default_rng(2).integers(0, 41, size=400)            # 41 categories -> one-hot (stm.py:665-671)
+    res = {}
+    for tag, X, cov in (("bin-moments", syn.X, "moments"), ("bin-exact", syn.X, "exact"), ("wide-moments", Xcat, "moments"),
+                        ("wide-exact", Xcat, "exact"), ("bin-host", syn.X, None), ("wide-host", Xcat, None)):
+        comm = sdist.RcclComm(sdist.TcpGroup(0, 1)) if cov else None
+        m = STM(documents=syn.corpus, dictionary=None, content=False, K=100, X=X, kappa_interactions=False, max_em_iter=2,
+                sigma_prior=0, convergence_threshold=1e-12, init_type="random", comm=comm)
+        if cov:
+            assert m._engine._h and m.comm.kind == "rccl"
+            m.cov_exchange = cov
+            m.expectation_maximization(saving=False)
+            assert m.cov_exchanges == [cov, cov]
+        else:
+            m.expectation_maximization(saving=False, resident=False)
+        res[tag] = (np.array(m.last_bounds), m.sigma.copy(), m.gamma.copy(), m.beta.copy())
+        m.close()
+    for kind in ("bin", "wide"):
+        ref = res[kind + "-host"]
+        for form in ("moments", "exact"):
+            got = res[f"{kind}-{form}"]
+            assert np.allclose(got[0], ref[0], rtol=1e-9), (kind, form)
+            assert np.allclose(got[1], ref[1], rtol=1e-6, atol=1e-9), (kind, form)
+            assert np.allclose(got[3], ref[3], rtol=1e-6, atol=1e-12), (kind, form)
+        assert res[kind + "-moments"][2].shape == ref[2].shape
+    assert np.allclose(res["bin-moments"][2], res["bin-host"][2], rtol=1e-6, atol=1e-8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_RANK_SCRIPT = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %(root)r)
+from strutopy_amd import STM, dist as sdist
+from strutopy_amd.corpus import PackedCorpus
+g = np.load(os.path.join(%(root)r, "tests", "golden", "c1_k10.npz"))
+full = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+group = sdist.init_from_env(timeout=120)
+comm = sdist.HostComm(group)
+lo, hi = sdist.shard_bounds(full.indptr, group.size)[group.rank]
+m = STM(documents=full.slice(lo, hi), dictionary=None, content=False, K=10, X=g["X"][lo:hi, 0], kappa_interactions=False,
+        max_em_iter=3, sigma_prior=0, convergence_threshold=1e-12, init_type="random", comm=comm, device=0)
+assert type(m._engine).__name__ == "HipEstepEngine" and m.N_total == full.N
+m.expectation_maximization(saving=False)
+np.savez(%(out)r + str(group.rank) + ".npz", lo=lo, hi=hi, bounds=np.array(m.last_bounds), sigma=m.sigma, beta=m.beta, eta=m.eta, mu=m.mu,
+         gamma=m.gamma, maps=np.array("libstm_hip.so" in open("/proc/self/maps").read()))
+comm.barrier()
+m.close()
+'''
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_fit(tmp_path):
+    """Two processes, each with its own stm_handle on GPU 0 and a contiguous document shard, exchanging the packed
+    sufficient statistics through the host group (TcpGroup: RCCL refuses two ranks on one device): exercises
+    stm_put_sigma_ss / stm_put_beta_ss, the sharded resident loop and the M-step from reduced moments on the HIP engine."""
+    from strutopy_amd import STM
+    g = load_golden("c1_k10")
+    port = _free_port()
+    script = _RANK_SCRIPT % dict(root=ROOT, out=str(tmp_path / "rank"))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", STM_RDZV_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    ref = STM(documents=_corpus(g), dictionary=None, content=False, K=10, X=g["X"][:, 0], kappa_interactions=False,
+              max_em_iter=3, sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    ref.expectation_maximization(saving=False)
+    res = [np.load(str(tmp_path / f"rank{r}.npz")) for r in range(2)]
+    assert int(res[0]["lo"]) == 0 and int(res[0]["hi"]) == int(res[1]["lo"]) and int(res[1]["hi"]) == ref.N
+    for r in res:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        assert bool(r["maps"])
+        assert np.allclose(r["bounds"], ref.last_bounds, rtol=1e-10)
+        assert np.allclose(r["sigma"], ref.sigma, rtol=1e-7, atol=1e-10)
+        assert np.allclose(r["beta"], ref.beta, rtol=1e-7, atol=1e-13)
+        assert np.allclose(r["gamma"], ref.gamma, rtol=1e-6, atol=1e-9)
+        assert np.allclose(r["eta"], ref.eta[lo:hi], atol=1e-7) and np.allclose(r["mu"], ref.mu[lo:hi], atol=1e-8)
+    assert np.array_equal(res[0]["sigma"], res[1]["sigma"]) and np.array_equal(res[0]["beta"], res[1]["beta"])
+    for it in range(3):
+        assert res[0]["bounds"][it] == pytest.approx(float(g[f"it{it}_bound"]), rel=1e-8)
+    ref.close()
+
+
+def test_bench_launches_its_own_ranks_and_strong_scaling_shards_one_corpus():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (device wrap-around on a one-GPU box, host
+    reduction because RCCL refuses duplicate devices) and reports n_gpus from the communicator; `--scaling strong`
+    shards ONE corpus, so its ELBO trace equals the single-rank one."""
+    def run(*extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "3000", "--vocab", "2000", "--topics", "20", "--steps", "2",
+               "--warmup", "1", "--cpu-sample", "0", *extra]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "STM_RDZV_PORT")}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+    one = run("--gpus", "1", "--scaling", "strong")
+    two = run("--gpus", "2", "--scaling", "strong")
+    weak = run("--gpus", "2")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and weak["n_gpus"] == 2
+    assert two["scaling"] == "strong" and weak["scaling"] == "weak"
+    assert two["config"]["docs_total"] == 3000 and weak["config"]["docs_total"] == 6000
+    assert np.allclose(two["elbo_trace"], one["elbo_trace"], rtol=1e-9)
+    assert weak["strong_scaling"]["docs_total"] == 3000
+    assert np.allclose(weak["strong_scaling"]["elbo_trace"], one["elbo_trace"], rtol=1e-9)
+    assert two["config"]["allreduces_per_iteration"] == 1
+    assert "roofline" in one and "roofline" not in two
+    for b in (one, two, weak):
+        assert b["value"] == pytest.approx(b["config"]["docs_total"] * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"]), rel=1e-6)
+
+
+# ------------------------------------------------------------------ the reference-side stub of INTEGRATION.md, executed
+def test_integration_stub_runs_against_a_reference_shaped_object():
+    """The ctypes stub INTEGRATION.md hands to a reference maintainer (section 2) is executed as written -- only the
+    library path is made absolute -- bound to a minimal object carrying the attributes the reference's E_step reads
+    (stm.py:489-597), and must reproduce the reference's own E-step results (tests/golden/c1_k10.npz)."""
+    from strutopy_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "class _Args(C.Structure)" in b)
+    stub = stub.replace('C.CDLL("libstm_hip.so")', f"C.CDLL({_lib.LIB_PATH!r})")
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    g = load_golden("c1_k10")
+
+    class RefShaped:      # what STM.__init__ of the reference leaves on self (stm.py:366-399, 412-476)
+        pass
+    m = RefShaped()
+    m.documents = _corpus(g).to_bow()
+    m.N, m.K, m.V = len(m.documents), int(g["K"]), int(g["V"])
+    m.beta, m.mu, m.eta = g["beta0"].copy(), g["it0_mu_in"].copy(), g["it0_eta_in"].copy()
+    m.sigma = g["it0_sigma_in"].copy()
+    m.betaindex, m.last_bounds = None, []
+    beta_ss, sigma_ss = ns["E_step"](m)
+    assert m.bound == pytest.approx(float(g["it0_bound"]), rel=1e-10) and m.last_bounds == [m.bound]
+    assert np.allclose(beta_ss, g["it0_beta_ss"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(sigma_ss, g["it0_sigma_ss"], rtol=1e-7)
+    assert np.max(np.abs(m.eta - g["it0_eta"])) <= 1e-7 and np.max(np.abs(m.theta - g["it0_theta"])) <= 1e-7
+    assert np.allclose(m.siginv, g["it0_siginv"])
+    # content covariate through the same stub (A = 2 levels, stm.py:527-528)
+    g = load_golden("content_a2")
+    m = RefShaped()
+    m.documents = _corpus(g).to_bow()
+    m.N, m.K, m.V = len(m.documents), int(g["K"]), int(g["V"])
+    m.beta, m.mu, m.eta, m.sigma = g["beta0"].copy(), g["it0_mu_in"].copy(), g["it0_eta_in"].copy(), g["it0_sigma_in"].copy()
+    m.betaindex, m.last_bounds = g["aspect"], []
+    beta_ss, _ = ns["E_step"](m)
+    assert m.bound == pytest.approx(float(g["it0_bound"]), rel=1e-10)
+    assert np.allclose(beta_ss, g["it0_beta_ss"], rtol=1e-7, atol=1e-12)
+    bad = RefShaped()
+    bad.__dict__.update(m.__dict__)
+    bad.beta = m.beta.copy(); bad.beta[0, 1, int(g["indices"][0])] = -1.0
+    bad.betaindex = np.ones(m.N, dtype=np.int64) * 0
+    with pytest.raises(AssertionError):       # stm.py:534
+        ns["E_step"](bad)

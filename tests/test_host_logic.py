@@ -110,6 +110,46 @@ def test_read_mm_roundtrip(tmp_path):
         assert dict(zip(r.indices[sl].tolist(), r.counts[sl].tolist())) == dict(zip(c.indices[sl].tolist(), c.counts[sl].tolist()))
 
 
+def test_read_mm_gensim_layout_and_the_shipped_wiki_corpus(tmp_path):
+    """gensim's MmCorpus writes a space-padded size line and entries grouped by document; the reference ships
+    src/artifacts/wiki_data/BoW_corpus.mm in that layout, and tests/golden/wiki_k50.npz holds its CSR."""
+    from strutopy_amd.corpus import read_mm
+    path = tmp_path / "bow.mm"
+    path.write_text("%%MatrixMarket matrix coordinate real general\n3 6 5                                  \n"
+                    "1 2 1\n1 5 3\n2 1 2\n3 6 1\n3 3 4\n")
+    c = read_mm(str(path))
+    assert c.N == 3 and c.V == 6 and c.indptr.tolist() == [0, 2, 3, 5]
+    assert c.indices.tolist() == [1, 4, 0, 5, 2] and c.counts.tolist() == [1, 3, 2, 1, 4]   # file order kept within a document
+    path.write_text("%%MatrixMarket matrix coordinate real general\n% a comment\n2 4 3\n2 1 1\n1 4 2\n2 3 5\n")
+    c = read_mm(str(path))                                           # not grouped by document: grouped stably
+    assert c.indptr.tolist() == [0, 1, 3] and c.indices.tolist() == [3, 0, 2] and c.counts.tolist() == [2, 1, 5]
+    path.write_text("%%MatrixMarket matrix coordinate real general\n2 4 1\n1 4 2\n")
+    with pytest.raises(IndexError):                                   # document 2 is empty (stm.py:523)
+        read_mm(str(path))
+    wiki = "/root/reference/src/artifacts/wiki_data/BoW_corpus.mm"   # only in the build container
+    if os.path.exists(wiki):
+        g = load_golden("wiki_k50")
+        w = read_mm(wiki)
+        assert w.V == int(g["V"]) and np.array_equal(w.indptr, g["indptr"])
+        assert np.array_equal(w.indices, g["indices"]) and np.array_equal(w.counts, g["counts"])
+
+
+def test_pack_bow_accepts_what_the_reference_accepts():
+    """np.array(documents[i]) (stm.py:522) takes tuples, lists or arrays of (id, count), integer or float counts."""
+    docs = [[(3, 2.0), (7, 1.0)], [[0, 5]], np.array([[1, 1], [2, 1], [9, 4]])]
+    c = pack_bow(docs, V=10)
+    assert c.indptr.tolist() == [0, 2, 3, 6] and c.indices.tolist() == [3, 7, 0, 1, 2, 9]
+    assert c.counts.tolist() == [2, 1, 5, 1, 1, 4]
+    big = synthetic_corpus(2000, 800, 5, n_words=60, seed=2).corpus
+    again = pack_bow(big.to_bow(), V=big.V)
+    assert np.array_equal(again.indptr, big.indptr) and np.array_equal(again.indices, big.indices)
+    assert np.array_equal(again.counts, big.counts)
+    with pytest.raises(IndexError):
+        pack_bow([[(1.5, 1)]], V=10)
+    with pytest.raises(IndexError):
+        pack_bow([[(-1, 1)]], V=10)
+
+
 # ----------------------------------------------------------------------------- STM mirror
 def test_constructor_state_matches_reference_init():
     g = load_golden("toy_ctm")
@@ -183,6 +223,47 @@ def test_content_covariate_levels(resident):
     assert m.last_bounds[0] == pytest.approx(float(g["it0_bound"]), rel=1e-10)
     assert m.last_bounds[1] == pytest.approx(float(g["it1_bound"]), rel=1e-8)
     assert np.allclose(m.beta, g["it1_beta_out"], rtol=1e-6, atol=1e-12)
+
+
+def test_covariance_from_moments_and_its_guard():
+    """One all-reduce: (eta - mu)^T (eta - mu) expanded in the reduced moments equals the direct product; when the
+    expansion would cancel more than four digits the resident loop takes the exact (second all-reduce) form."""
+    g = load_golden("c1_k10")
+    m = _model(g, "STM", 2)
+    rng = np.random.default_rng(0)
+    N, n, p = 500, 9, 3
+    X = rng.integers(0, 2, size=(N, p)).astype(float)
+    eta = rng.normal(0, 1, size=(N, n)) + X @ rng.normal(size=(p, n))
+    m.gamma = rng.normal(size=(n, p))
+    cov, ratio = m._covariance_from_moments(eta.T @ eta, N, eta.sum(0), X.T @ X, X.T @ eta)
+    d = eta - X @ m.gamma.T
+    assert np.allclose(cov, d.T @ d, rtol=1e-11, atol=1e-9) and np.allclose(cov, cov.T, rtol=0, atol=1e-10) and 0 < ratio
+    cov, ratio = m._covariance_from_moments(eta.T @ eta, N, eta.sum(0))          # CTM: mu = column mean
+    d = eta - eta.mean(0)
+    assert np.allclose(cov, d.T @ d, rtol=1e-11, atol=1e-9)
+    far = 1e4 + 1e-3 * rng.normal(size=(N, n))                                   # eta^T eta ~ 1e10, covariance ~ 1e-4
+    _, ratio = m._covariance_from_moments(far.T @ far, N, far.sum(0))
+    assert ratio < 1e-4
+    # both forms through the resident loop
+    out = {}
+    for form in ("moments", "exact"):
+        mm = _model(g, "STM", 2)
+        mm.cov_exchange = form
+        mm.expectation_maximization(saving=False)
+        assert mm.cov_exchanges == [form, form]
+        out[form] = (mm.sigma.copy(), np.array(mm.last_bounds))
+    assert np.allclose(out["moments"][0], out["exact"][0], rtol=1e-9, atol=1e-12)
+    assert np.allclose(out["moments"][1], out["exact"][1], rtol=1e-12)
+
+
+def test_unknown_mode_falls_back_to_ols_like_the_reference(capsys):
+    g = load_golden("c1_k10")
+    a, b = _model(g, "STM", 1, mode="foo"), _model(g, "STM", 1)
+    a.expectation_maximization(saving=False)          # resident path; stm.py:696-700 prints a notice and uses OLS
+    b.expectation_maximization(saving=False)
+    assert "default 'ols'" in capsys.readouterr().out
+    assert np.allclose(a.gamma, b.gamma, rtol=1e-12) and np.allclose(a.sigma, b.sigma, rtol=1e-12)
+    assert a.phi is not None and a.phi.shape[0] == int(g["K"])   # self.phi is populated after a resident iteration too
 
 
 def test_em_driver_convergence_and_caps():

@@ -62,6 +62,27 @@ def test_estep_matches_reference(oracle, name, its):
         assert _rel(o["phi_last"], g[p + "phi_last"]) <= 1e-8
 
 
+def test_k50_later_iterations_teacher_forced(oracle):
+    """tests/golden/k50_late.npz (tools/make_golden.py k50_late): EM iterations 3, 4, 5, 8 of the reference at
+    K=50 / V=10k with each E-step's full input state -- the regime where about half of the documents take BFGS
+    steps that move (iterations 0-1 of the other K=50 goldens never do)."""
+    g = load_golden("k50_late")
+    moved = 0
+    for it in g["kept"]:
+        p = f"it{int(it)}_"
+        o = oracle.estep(g["indptr"], g["indices"], g["counts"], g[p + "beta_in"], g[p + "mu_in"], g[p + "eta_in"],
+                         g[p + "siginv"], float(g[p + "sigmaentropy"]), nthreads=0)
+        for k in ("status", "nit", "pd_path"):
+            assert np.array_equal(o[k], g[p + k]), f"it{it}: {k}"
+        assert np.max(np.abs(o["eta"] - g[p + "eta"])) <= 1e-7
+        assert np.max(np.abs(o["bound_doc"] - g[p + "bound_doc"]) / np.abs(g[p + "bound_doc"])) <= 1e-9
+        assert abs(o["bound"] - float(g[p + "bound"])) <= 1e-10 * abs(float(g[p + "bound"]))
+        assert _rel(o["sigma_ss"], g[p + "sigma_ss"]) <= 1e-8
+        assert _rel(o["beta_ss"].sum(axis=1), g[p + "beta_ss_rowsum"]) <= 1e-9
+        moved += int(np.sum(g[p + "nit"] > 0))
+    assert moved > 2000          # it 4: 41 %, it 5: 100 %, it 8: 116 % BFGS iterations per document
+
+
 def test_wiki_known_answer_shipped_by_reference(oracle):
     """ELBO[0] of src/artifacts/reference_model/50/lower_bound.pickle: the one number the
     reference itself ships for this path."""

@@ -431,9 +431,54 @@ def case_heldout():
          mean=np.float64(mean), per_doc=per_doc)
 
 
+def case_k50_late():
+    """BASELINE config 1 shape at 2000 documents, LATER EM iterations: from iteration 4 on about half of the
+    documents take BFGS steps that move (successful line searches), which iterations 0-1 of the other K=50
+    goldens never exercise.  Nine EM iterations of the reference; for iterations 3, 4, 5 and 8 the complete
+    E-step input state (beta, eta, mu, siginv) and per-document outputs are kept, so that oracle and HIP path
+    can be TEACHER-FORCED (the reference's free-running trajectory is chaotic)."""
+    K, keep = 50, (3, 4, 5, 8)
+    c = _synthetic(K, 10000, 2000, 4242)
+    docs = c.documents
+    m = make_model(docs, c.dictionary, K, c.metadata, max_em_iter=9)
+    V = len(c.dictionary)
+    out = {}
+    for it in range(9):
+        m._rec_reset()
+        p = f"it{it}_"
+        if it in keep:
+            out[p + "beta_in"] = np.asarray(m.beta).copy()
+            out[p + "eta_in"] = m.eta.copy()
+            out[p + "mu_in"] = m.mu.copy()
+        t = time.time()
+        beta_ss, sigma_ss = m.E_step()
+        te = time.time() - t
+        out[p + "bound"] = np.float64(m.bound)
+        out[p + "nit_mean"] = np.float64(np.mean(m.rec["nit"]))
+        out[p + "nfev_mean"] = np.float64(np.mean(m.rec["nfev"]))
+        if it in keep:
+            out[p + "siginv"] = np.asarray(m.siginv)
+            out[p + "sigmaentropy"] = np.float64(m.sigmaentropy)
+            out[p + "eta"] = m.eta.copy()
+            out[p + "theta"] = m.theta.copy()
+            out[p + "bound_doc"] = np.asarray(m.rec["bound"])
+            for k in ("status", "nit", "nfev", "njev", "pd_path"):
+                out[p + k] = np.asarray(m.rec[k], dtype=np.int32)
+            out[p + "sigma_ss"] = sigma_ss.copy()
+            out[p + "beta_ss_rowsum"] = beta_ss.sum(axis=-1)
+            out[p + "beta_ss_colsum"] = beta_ss.sum(axis=-2)
+        m.M_step(beta_ss, sigma_ss)
+        print(f"    it{it}: bound={m.bound!r} estep={te:.1f}s status2={np.mean(np.asarray(m.rec['status']) == 2):.3f} "
+              f"nit_mean={np.mean(m.rec['nit']):.3f} nfev_mean={np.mean(m.rec['nfev']):.1f} "
+              f"pd_path={np.bincount(m.rec['pd_path'], minlength=3)}")
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("k50_late", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(c.metadata, dtype=np.float64),
+         K=np.int32(K), V=np.int32(V), kept=np.asarray(keep, dtype=np.int32), **out)
+
+
 CASES = dict(toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
-             wiki_k50=case_wiki_k50)
+             wiki_k50=case_wiki_k50, k50_late=case_k50_late)
 
 if __name__ == "__main__":
     import logging
