@@ -385,12 +385,19 @@ def test_rccl_all_reduce_path_single_rank():
     bound = e.estep(g["it0_siginv"], float(g["it0_sigmaentropy"]))
     beta_ss, sigma_ss = e.get_beta_ss(), e.get_sigma_ss()
     e.comm_init(e.comm_unique_id(), 0, 1)
-    extra = np.arange(1.0, 40.0)
-    b2, extra2 = e.allreduce_suffstats(extra)
-    assert b2 == bound and np.array_equal(extra2, extra)
+    e.put_covariates(g["X"][:, :1])
+    mom = e.moments(1)                    # left in the moment region of the packed buffer: [N | sx | se | XtX | Xte | ete]
+    n = int(g["K"]) - 1
+    eta, X = e.get_eta(), g["X"][:, :1]
+    want = np.concatenate([[len(eta)], X.sum(0), eta.sum(0), (X.T @ X).ravel(), (X.T @ eta).ravel(), (eta.T @ eta).ravel()])
+    assert mom.shape == (1 + 1 + n + 1 + n + n * n,) and np.allclose(mom, want, rtol=1e-12, atol=1e-9)
+    b2, mom2 = e.allreduce_suffstats(mom)
+    assert b2 == bound and np.array_equal(mom2, mom)
     assert np.array_equal(e.get_beta_ss(), beta_ss) and np.array_equal(e.get_sigma_ss(), sigma_ss)
     small = np.linspace(-1, 1, 81).reshape(9, 9)
     assert np.array_equal(e.allreduce_small(small), small)
+    big = np.linspace(-1, 1, 127 * 127)   # any length: its own device buffer (K >= 66 did not fit)
+    assert np.array_equal(e.allreduce_small(big), big)
     e.close()
 
 

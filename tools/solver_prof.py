@@ -7,14 +7,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from strutopy_amd import STM, _lib
 from strutopy_amd.corpus import synthetic_corpus
-ND, VV, KK = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (20000, 10000, 50)))   # docs V K
+ND, VV, KK = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (20000, 10000, 50)))   # docs V K [iterations [first printed]]
+ITS = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+FIRST = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 syn = synthetic_corpus(ND, VV, KK, n_words=150, seed=12345)
-m = STM(documents=syn.corpus, dictionary=None, content=False, K=KK, X=syn.X, kappa_interactions=False, max_em_iter=2,
+m = STM(documents=syn.corpus, dictionary=None, content=False, K=KK, X=syn.X, kappa_interactions=False, max_em_iter=ITS,
         sigma_prior=0, convergence_threshold=1e-9, init_type="random")
-for it in range(2):
+for it in range(ITS):
     m._em_iteration_resident()
     out = np.zeros((m.N, 40), dtype=np.int64)
     _lib.check(_lib.lib().stm_debug_get_prof(m._engine._h, out.ctypes.data_as(C.POINTER(C.c_longlong))))
+    if it < FIRST:
+        continue
     d = m.solver_diagnostics()
     tot = out[:, :4].sum(1)
     print(f"it{it}: cycles/doc init {out[:,0].mean():.0f} eval {out[:,1].mean():.0f} sm {out[:,2].mean():.0f} upd {out[:,3].mean():.0f} total {tot.mean():.0f}"
