@@ -139,6 +139,26 @@ int stm_mstep_update_beta(stm_handle *h);
 int stm_eval_heldout(stm_handle *h, int64_t N, const int64_t *indptr, const int32_t *indices,
                      const double *counts, const double *theta, double *doc_ll);
 
+/* ---- spectral initialisation (next-row f-4; reference src/modules/stm.py:30-296) ---- */
+/* gram (stm.py:122-157): Q = Htilde^T Htilde - diag(Hhat) over the Vk kept terms, dense and resident on the
+ * handle.  The caller passes the kept part of the document-term matrix in both orientations -- per document
+ * (doc_ptr[N+1], doc_word, doc_h) and per term (word_ptr[Vk+1], word_doc ascending, word_h) -- with
+ * h = count / sqrt(n_d (n_d - 1)), n_d the document's length over the kept terms, and hhat[w] = sum_d
+ * count_dw / (n_d (n_d - 1)).  STM_ERR_BETA mirrors the reference's assert on the row sums (stm.py:152-154).
+ * As imported with scikit-learn >= 1.x the reference's row normalisation (stm.py:156) acts on a discarded
+ * copy: Q stays unnormalised, here too. */
+int stm_spectral_gram(stm_handle *h, int64_t N, int32_t Vk, const int64_t *doc_ptr, const int32_t *doc_word,
+                      const double *doc_h, const int64_t *word_ptr, const int32_t *word_doc, const double *word_h,
+                      const double *hhat);
+/* rows of the matrix fastAnchor's caller holds: gram's result, after stm_spectral_anchors with the first
+ * anchor's row rescaled (stm.py:185 modifies the caller's matrix in its first round) */
+int stm_spectral_get_q(stm_handle *h, const int32_t *rows, int32_t nrows, double *out /* [nrows][Vk] */);
+/* fastAnchor (stm.py:160-226): K greedy anchor terms (indices into the kept terms) */
+int stm_spectral_anchors(stm_handle *h, int32_t K, int32_t *anchor /* [K] out */);
+/* the per-word QP inputs of recover_l2 (stm.py:239-270): q[i][k] = Q[i] . Q[anchor[k]]; P = q[anchor] */
+int stm_spectral_project(stm_handle *h, int32_t K, const int32_t *anchor, double *q_out /* [Vk][K] */);
+int stm_spectral_release(stm_handle *h);
+
 /* ---- multi-GPU: one RCCL all-reduce of the sufficient statistics ------- */
 /* rank 0 calls stm_comm_unique_id and ships the 128 bytes to the other ranks
  * (any side channel); then every rank calls stm_comm_init. */

@@ -64,6 +64,11 @@ SIGNATURES = {
     "stm_mstep_covariance": (C.c_int, [_h, _dp]),
     "stm_mstep_update_beta": (C.c_int, [_h]),
     "stm_eval_heldout": (C.c_int, [_h, C.c_int64, _lp, _ip, _dp, _dp, _dp]),
+    "stm_spectral_gram": (C.c_int, [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _lp, _ip, _dp, _dp]),
+    "stm_spectral_get_q": (C.c_int, [_h, _ip, C.c_int32, _dp]),
+    "stm_spectral_anchors": (C.c_int, [_h, C.c_int32, _ip]),
+    "stm_spectral_project": (C.c_int, [_h, C.c_int32, _ip, _dp]),
+    "stm_spectral_release": (C.c_int, [_h]),
     "stm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "stm_comm_init": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
     "stm_allreduce_suffstats": (C.c_int, [_h, _dp, _dp, C.c_int64]),

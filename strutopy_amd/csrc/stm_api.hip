@@ -136,6 +136,7 @@ struct stm_handle {
     size_t extra_cap = 0, small_len = 0;
     double *d_ascratch = nullptr; size_t ascratch_len = 0;   // post_big_kernel's per-workgroup A
     size_t pack_len = 0;
+    void *spectral = nullptr;   // spectral-initialisation workspace (stm_spectral_api.inc)
     // timing
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float ms[3] = {0, 0, 0};
@@ -145,6 +146,8 @@ struct stm_handle {
     void *stage = nullptr;
     static constexpr size_t STAGE_BYTES = 1 << 20;
 };
+
+void stm_spectral_destroy(void *p);
 
 static int use_device(stm_handle *h) {
     HIP_TRY(hipSetDevice(h->device));
@@ -284,6 +287,7 @@ void stm_destroy(stm_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     stm_mstep_comm_destroy(h->comm);
+    stm_spectral_destroy(h->spectral);
     dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
     dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_eta); dfree(h->d_mu);
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
@@ -717,3 +721,4 @@ int stm_estep_host(const stm_estep_args *a, int device_ordinal) {
 }  // extern "C"
 
 #include "stm_mstep_api.inc"
+#include "stm_spectral_api.inc"

@@ -1,0 +1,145 @@
+// stm_spectral.h -- device side of the spectral initialisation (reference src/modules/stm.py:30-296,
+// the init_type src/05_train.py:92 uses).
+//
+//   gram_kernel        Q = Htilde^T Htilde - diag(Hhat) (stm.py:122-157) as a dense Vk x Vk matrix, one workgroup
+//                      per word: the word's row is accumulated in LDS over the documents that contain it, in
+//                      ascending document order (the order scipy's sparse product adds them in) -- no atomics,
+//                      run-to-run identical
+//   fastAnchor pieces  (stm.py:160-226) column sums of squares, first-maximum search, row scaling,
+//                      Q @ Q[m]^T, rank-one projection off every row outside `basis`
+//   project_kernel     q_i = M y_i for every word i (M = anchor rows; stm.py:239, :266-270): the inputs of the
+//                      per-word QP, whose K x K solves stay on the host
+// All HBM-bound streaming passes over the 8 Vk^2-byte matrix (200 MB at maxV = 5000).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stm_wave.h"
+
+namespace stm {
+
+// one workgroup per word a (row of Q); dynamic LDS: row[Vk]
+__global__ __launch_bounds__(256) void gram_kernel(const int64_t *doc_ptr, const int32_t *doc_word, const double *doc_h,
+                                                   const int64_t *word_ptr, const int32_t *word_doc, const double *word_h,
+                                                   const double *hhat, int Vk, double *Q, int32_t *err_flag) {
+    extern __shared__ double grow[];
+    const int a = blockIdx.x;
+    for (int c = threadIdx.x; c < Vk; c += blockDim.x) grow[c] = 0.0;
+    __syncthreads();
+    const int64_t w0 = word_ptr[a], w1 = word_ptr[a + 1];
+    for (int64_t e = w0; e < w1; ++e) {          // documents containing word a, ascending
+        const int d = word_doc[e];
+        const double ha = word_h[e];
+        const int64_t p0 = doc_ptr[d], p1 = doc_ptr[d + 1];
+        for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x)   // words of a document are unique: no two threads share a cell
+            grow[doc_word[p]] += ha * doc_h[p];
+        __syncthreads();                          // the next document may touch the same cells from other threads
+    }
+    if (threadIdx.x == 0) grow[a] -= hhat[a];
+    __syncthreads();
+    // assert np.all(Q.sum(axis=1) > 0) (stm.py:152-154): fixed-order block sum
+    __shared__ double part[256];
+    double t = 0.0;
+    for (int c = threadIdx.x; c < Vk; c += blockDim.x) {
+        const double v = grow[c];
+        Q[(size_t)a * Vk + c] = v;
+        t += v;
+    }
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && !(part[0] > 0.0)) atomicMax(err_flag, 1);
+}
+
+// partial column sums of squares: part[blockIdx.y][c] = sum over the block's rows of Q[r][c]^2
+__global__ __launch_bounds__(256) void colsq_kernel(const double *Q, int Vk, double *part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = (Vk + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * chunk, r1 = r0 + chunk < Vk ? r0 + chunk : Vk;
+    if (c >= Vk) return;
+    double t0 = 0.0, t1 = 0.0;
+    int r = r0;
+    for (; r + 1 < r1; r += 2) {
+        const double a = Q[(size_t)r * Vk + c], b = Q[(size_t)(r + 1) * Vk + c];
+        t0 += a * a; t1 += b * b;
+    }
+    if (r < r1) { const double a = Q[(size_t)r * Vk + c]; t0 += a * a; }
+    part[(size_t)blockIdx.y * Vk + c] = t0 + t1;
+}
+
+// row_squared_sum[:, basis] = 0 (stm.py:222; `basis` still holds zeros for the anchors not chosen yet, so entry 0 goes
+// too), then the FIRST index of the maximum (np.argmax) and 1 / sqrt(max) (stm.py:181-184).  One block.
+__global__ __launch_bounds__(1024) void anchor_pick_kernel(double *rss, int Vk, const int32_t *basis, int nbasis, int zero_first,
+                                                           int32_t *pick, double *normalizer) {
+    __shared__ double bv[1024];
+    __shared__ int bi[1024];
+    if (zero_first) {
+        for (int q = threadIdx.x; q < nbasis; q += 1024) rss[basis[q]] = 0.0;
+        __syncthreads();
+    }
+    double best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int c = threadIdx.x; c < Vk; c += 1024) {
+        const double v = rss[c];
+        if (v > best || (v == best && c < arg)) { best = v; arg = c; }
+    }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = arg;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double v = bv[threadIdx.x + o];
+            const int c = bi[threadIdx.x + o];
+            if (v > bv[threadIdx.x] || (v == bv[threadIdx.x] && c < bi[threadIdx.x])) { bv[threadIdx.x] = v; bi[threadIdx.x] = c; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *pick = bi[0]; *normalizer = 1.0 / sqrt(bv[0]); }
+}
+
+// Q[m] = Q[m] * normalizer (stm.py:185); m and the factor are read from device memory
+__global__ void scale_row_kernel(double *Q, int Vk, const int32_t *pick, const double *normalizer) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < Vk) Q[(size_t)(*pick) * Vk + c] *= *normalizer;
+}
+
+// inner[r] = Q[r] . Q[m] (stm.py:188-193): one wavefront per row, fixed order
+__global__ __launch_bounds__(64) void row_dot_kernel(const double *Q, int Vk, const int32_t *pick, double *inner) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const double *a = Q + (size_t)r * Vk, *b = Q + (size_t)(*pick) * Vk;
+    double t0 = 0.0, t1 = 0.0;
+    int c = lane;
+    for (; c + 64 < Vk; c += 128) { t0 = fma(a[c], b[c], t0); t1 = fma(a[c + 64], b[c + 64], t1); }
+    if (c < Vk) t0 = fma(a[c], b[c], t0);
+    const double t = wave_sum(t0 + t1);
+    if (lane == 0) inner[r] = t;
+}
+
+// Q[r] -= inner[r] * Q[m] for every row r outside `basis` (stm.py:205-217); skip[r] != 0 marks the excluded rows
+__global__ __launch_bounds__(256) void project_off_kernel(double *Q, int Vk, const int32_t *pick, const double *inner, const uint8_t *skip) {
+    const int r = blockIdx.y;
+    if (skip[r]) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Vk) return;
+    Q[(size_t)r * Vk + c] -= inner[r] * Q[(size_t)(*pick) * Vk + c];
+}
+
+// q[i][k] = Q[i] . M[k], M[k] = Q[anchor[k]] (stm.py:239, 266-270): one wavefront per word i, its row held in registers
+// in chunks of 64 * RCH columns
+__global__ __launch_bounds__(64) void anchor_project_kernel(const double *Q, int Vk, const int32_t *anchor, int K, double *q) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double *a = Q + (size_t)i * Vk;
+    for (int k = 0; k < K; ++k) {
+        const double *b = Q + (size_t)anchor[k] * Vk;
+        double t0 = 0.0, t1 = 0.0;
+        int c = lane;
+        for (; c + 64 < Vk; c += 128) { t0 = fma(a[c], b[c], t0); t1 = fma(a[c + 64], b[c + 64], t1); }
+        if (c < Vk) t0 = fma(a[c], b[c], t0);
+        const double t = wave_sum(t0 + t1);
+        if (lane == 0) q[(size_t)i * K + k] = t;
+    }
+}
+
+}  // namespace stm

@@ -194,6 +194,33 @@ class HipEstepEngine:
                                        dptr(th) if th is not None else None, dptr(out)))
         return out
 
+    # -- spectral initialisation (stm.py:30-296) ----------------------------------------------
+    def spectral_gram(self, N, Vk, g):
+        a = {k: np.ascontiguousarray(v) for k, v in g.items()}
+        check(self._L.stm_spectral_gram(self._h, int(N), int(Vk), lptr(a["doc_ptr"]), iptr(a["doc_word"]), dptr(a["doc_h"]),
+                                        lptr(a["word_ptr"]), iptr(a["word_doc"]), dptr(a["word_h"]), dptr(f64(a["hhat"]))))
+        self._Vk = int(Vk)
+
+    def spectral_q_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        out = np.empty((len(rows), self._Vk))
+        check(self._L.stm_spectral_get_q(self._h, iptr(rows), len(rows), dptr(out)))
+        return out
+
+    def spectral_anchors(self, K):
+        out = np.zeros(int(K), dtype=np.int32)
+        check(self._L.stm_spectral_anchors(self._h, int(K), iptr(out)))
+        return out
+
+    def spectral_project(self, anchor):
+        anchor = np.ascontiguousarray(anchor, dtype=np.int32)
+        out = np.empty((self._Vk, len(anchor)))
+        check(self._L.stm_spectral_project(self._h, len(anchor), iptr(anchor), dptr(out)))
+        return out
+
+    def spectral_release(self):
+        check(self._L.stm_spectral_release(self._h))
+
     # -- multi-GPU ---------------------------------------------------------------------
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)

@@ -12,8 +12,8 @@ The E-step runs in hand-written HIP kernels behind the C-ABI of
 include/stm_estep.h; host code is Python + NumPy + ctypes.  There is no CPU
 fallback: constructing an STM without a usable GPU / built library raises.
 
-Out of scope (raise NotImplementedError): spectral initialisation
-(stm.py:30-296, needs the absent `qpsolvers`), `mnreg` (`lda_beta=False`,
+`init_type="spectral"` (stm.py:30-296) runs through strutopy_amd.spectral (gram / fastAnchor on the GPU).
+Out of scope (raise NotImplementedError): `mnreg` (`lda_beta=False`,
 stm.py:749-853, broken in the reference on current scipy), labelling/plot helpers.
 """
 import logging
@@ -193,9 +193,12 @@ class STM:
 
     def init_beta(self):
         if self.init == "spectral":
-            raise NotImplementedError(
-                "spectral initialisation (reference stm.py:30-296) is outside the accelerated hot path; "
-                "use init_type='random' or assign `model.beta` before fitting")
+            if self.comm.size > 1:
+                raise NotImplementedError("spectral initialisation needs the whole corpus on one rank: initialise once, "
+                                          "then hand beta to the sharded models")
+            from .spectral import spectral_init
+            # stm.py:419-422; a 2-D beta also when kappa_interactions is set, like the reference
+            self.beta = spectral_init(self._corpus, self.K, self.V, maxV=5000, verbose=False, engine=self._engine)
         elif self.init == "random":
             # stm.py:425-439, numpy legacy RNG stream seeded at stm.py:361
             beta_init = np.random.gamma(0.1, 1, self.V * self.K).reshape(self.K, self.V)

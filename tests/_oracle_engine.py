@@ -87,3 +87,22 @@ class OracleEngine:
 
     def allreduce_small(self, buf):
         return np.array(buf, dtype=np.float64, copy=True)
+
+    # ---- spectral initialisation: the NumPy restatement (oracle/spectral_oracle.py) behind the engine's interface
+    def spectral_gram(self, N, Vk, g):
+        from oracle import spectral_oracle as so
+        indptr = np.asarray(g["doc_ptr"])
+        D = np.zeros((N, Vk))
+        doc = np.repeat(np.arange(N), np.diff(indptr))
+        D[doc, g["doc_word"]] = g["doc_h"]
+        self._sq0 = D.T @ D - np.diag(g["hhat"])
+        assert np.all(self._sq0.sum(axis=1) > 0), "Encountered zeroes in Q row sums, can not normalize."
+        self._so = so
+
+    def spectral_anchors(self, K):
+        anchor, self._sq0 = self._so.fast_anchor(self._sq0, K)
+        return np.asarray(anchor, dtype=np.int32)
+
+    def spectral_q_rows(self, rows): return self._sq0[np.intp(rows)].copy()
+    def spectral_project(self, anchor): return self._sq0 @ self._sq0[np.intp(anchor)].T
+    def spectral_release(self): self._sq0 = None

@@ -289,9 +289,9 @@ def test_save_model_layout(tmp_path):
 
 def test_error_behaviour_matches_reference():
     g = load_golden("toy_ctm")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):       # neither of the reference's two init types
         STM(documents=_corpus(g), dictionary=None, content=False, K=3, X=g["X"][:, 0], kappa_interactions=False,
-            max_em_iter=1, sigma_prior=0, convergence_threshold=1e-5, init_type="spectral", engine=OracleEngine())
+            max_em_iter=1, sigma_prior=0, convergence_threshold=1e-5, init_type="kmeans", engine=OracleEngine())
     with pytest.raises(ValueError):       # stm.py:389-390
         STM(documents=_corpus(g), dictionary=None, content=False, K=0, X=None, kappa_interactions=False,
             max_em_iter=1, sigma_prior=0, convergence_threshold=1e-5, init_type="random", engine=OracleEngine())

@@ -476,9 +476,63 @@ def case_k50_late():
          K=np.int32(K), V=np.int32(V), kept=np.asarray(keep, dtype=np.int32), **out)
 
 
+def _spectral_parts(docs, K, V, maxV=5000):
+    """The reference's spectral_init (stm.py:30-85), statement by statement, keeping the intermediate results."""
+    dtm = ref_stm.create_dtm(corpus=docs)
+    wprob = np.sum(dtm, axis=0)
+    wprob = wprob / np.sum(wprob)
+    wprob = np.array(wprob).flatten()
+    keep = np.argsort(-1 * wprob)[:maxV]
+    dtm = dtm[:, keep]
+    wprob = wprob[keep]
+    Q = ref_stm.gram(dtm)
+    Q_gram = Q.toarray()
+    anchor = ref_stm.fastAnchor(Q, K, verbose=False)
+    Q_caller = Q.toarray()                       # fastAnchor rescales one row of the caller's matrix
+    beta = ref_stm.recover_l2(Q, anchor, wprob)   # qpsolvers.solve_qp: tools/refshim stand-in (see its docstring)
+    full = ref_stm.spectral_init(docs, K, V, maxV=maxV, verbose=False)
+    return dict(wprob=wprob, keep=keep, Q_gram=Q_gram, anchor=np.asarray(anchor), Q_caller=Q_caller,
+                beta_kept=np.asarray(beta), beta=np.asarray(full))
+
+
+def case_spectral_c1():
+    """Spectral initialisation (stm.py:30-296; the init src/05_train.py:92 uses) on the C1-shaped corpus, K = 10."""
+    g = np.load(os.path.join(OUT, "c1_k10.npz"))
+    indptr, idx, cnt = g["indptr"], g["indices"], g["counts"]
+    docs = [list(zip(idx[indptr[i]:indptr[i + 1]].tolist(), cnt[indptr[i]:indptr[i + 1]].astype(np.int64).tolist()))
+            for i in range(len(indptr) - 1)]
+    K, V = 10, int(g["V"])
+    r = _spectral_parts(docs, K, V)
+    rows = np.linspace(0, V - 1, 48).astype(np.int64)
+    save("spectral_c1", K=np.int32(K), V=np.int32(V), corpus=np.asarray("c1_k10"), wprob=r["wprob"], keep=r["keep"],
+         anchor=r["anchor"], sample_rows=rows, Q_gram_rows=r["Q_gram"][rows], Q_gram_rowsum=r["Q_gram"].sum(axis=1),
+         Q_gram_colsq=(r["Q_gram"] ** 2).sum(axis=0), Q_caller_anchor_rows=r["Q_caller"][np.intp(r["anchor"])],
+         beta_kept=r["beta_kept"], beta=r["beta"], qp_solver=np.asarray("tools/refshim qpsolvers stand-in (scipy nnls)"))
+
+
+def case_spectral_wiki():
+    """Spectral initialisation on the shipped wiki corpus (V = 13852 > maxV = 5000: the frequency cut is exercised),
+    K = 50 as in src/03_fit_reference_model.py."""
+    g = np.load(os.path.join(OUT, "wiki_k50.npz"))
+    indptr, idx, cnt = g["indptr"], g["indices"], g["counts"]
+    docs = [list(zip(idx[indptr[i]:indptr[i + 1]].tolist(), cnt[indptr[i]:indptr[i + 1]].tolist()))
+            for i in range(len(indptr) - 1)]
+    K, V = 50, int(g["V"])
+    r = _spectral_parts(docs, K, V)
+    Vk = len(r["keep"])
+    rows = np.linspace(0, Vk - 1, 24).astype(np.int64)
+    cols = np.linspace(0, V - 1, 64).astype(np.int64)
+    save("spectral_wiki", K=np.int32(K), V=np.int32(V), corpus=np.asarray("wiki_k50"), wprob=r["wprob"], keep=r["keep"],
+         anchor=r["anchor"], sample_rows=rows, Q_gram_rows=r["Q_gram"][rows], Q_gram_rowsum=r["Q_gram"].sum(axis=1),
+         Q_gram_colsq=(r["Q_gram"] ** 2).sum(axis=0), beta_rowsum=r["beta"].sum(axis=1), beta_colsum=r["beta"].sum(axis=0),
+         sample_cols=cols, beta_cols=r["beta"][:, cols], beta_kept_anchor_cols=r["beta_kept"][:, np.intp(r["anchor"])],
+         qp_solver=np.asarray("tools/refshim qpsolvers stand-in (scipy nnls)"))
+
+
 CASES = dict(toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
-             wiki_k50=case_wiki_k50, k50_late=case_k50_late)
+             wiki_k50=case_wiki_k50, k50_late=case_k50_late, spectral_c1=case_spectral_c1,
+             spectral_wiki=case_spectral_wiki)
 
 if __name__ == "__main__":
     import logging
