@@ -131,6 +131,17 @@ int stm_mstep_covariance(stm_handle *h, double *cov /* [(K-1)^2] */);
  * beta_ss held on the device */
 int stm_mstep_update_beta(stm_handle *h);
 
+/* One EM iteration on resident state with ONE host wait (what STM.expectation_maximization runs):
+ *   stm_em_begin   enqueues the E-step (as stm_estep), the moments (as stm_mstep_moments) and, when a communicator is
+ *                  attached, the all-reduce of the packed buffer; waits once; returns the (reduced) bound, sigma_ss
+ *                  and moments, and reports the E-step's errors like stm_estep.
+ *   stm_em_finish  enqueues mu (regression on gamma, or the constant mean_eta when gamma == NULL) and beta from the
+ *                  (reduced) beta_ss -- stm_mstep_set_mu + stm_mstep_update_beta without their waits; whatever is called
+ *                  next on the handle is ordered behind them. */
+int stm_em_begin(stm_handle *h, const double *siginv, double sigmaentropy, double *bound_total,
+                 double *sigma_ss /* [(K-1)^2] */, double *moments, int64_t moments_cap);
+int stm_em_finish(stm_handle *h, const double *gamma /* [(K-1)][p], nullable */, const double *mean_eta /* [(K-1)] */);
+
 /* ---- held-out likelihood (next-row f-3) -------------------------------- */
 /* eval_heldout(heldout, theta, beta) of src/modules/heldout.py:88-97 against the beta resident on the
  * handle: doc_ll[d] = sum_w c_w log(theta_d . beta[:, w]) / sum_w c_w for the documents given as CSR

@@ -63,6 +63,8 @@ SIGNATURES = {
     "stm_mstep_set_mu": (C.c_int, [_h, _dp, _dp]),
     "stm_mstep_covariance": (C.c_int, [_h, _dp]),
     "stm_mstep_update_beta": (C.c_int, [_h]),
+    "stm_em_begin": (C.c_int, [_h, _dp, C.c_double, _dp, _dp, _dp, C.c_int64]),
+    "stm_em_finish": (C.c_int, [_h, _dp, _dp]),
     "stm_eval_heldout": (C.c_int, [_h, C.c_int64, _lp, _ip, _dp, _dp, _dp]),
     "stm_spectral_gram": (C.c_int, [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _lp, _ip, _dp, _dp]),
     "stm_spectral_get_q": (C.c_int, [_h, _ip, C.c_int32, _dp]),

@@ -145,6 +145,10 @@ struct stm_handle {
     // a copy to / from fresh pageable memory makes the runtime pin the caller's pages on the fly (ms)
     void *stage = nullptr;
     static constexpr size_t STAGE_BYTES = 1 << 20;
+    // pinned regions of the single-synchronisation EM iteration (stm_em_begin / stm_em_finish), so that nothing enqueued
+    // there shares a staging area with a transfer still in flight: [0, 1M) read-back, [1M, 1.5M) siginv, [1.5M, 2M) gamma
+    void *stage_em = nullptr;
+    static constexpr size_t EM_BACK = 1 << 20, EM_SIG = 1 << 19, EM_GAM = 1 << 19;
 };
 
 void stm_spectral_destroy(void *p);
@@ -278,6 +282,7 @@ int stm_create(stm_handle **out, int device_ordinal) {
     for (auto &ev : h->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipEventCreate failed"); }
     if (hipHostMalloc(&h->stage, stm_handle::STAGE_BYTES, hipHostMallocDefault) != hipSuccess) h->stage = nullptr;
+    if (hipHostMalloc(&h->stage_em, stm_handle::EM_BACK + stm_handle::EM_SIG + stm_handle::EM_GAM, hipHostMallocDefault) != hipSuccess) h->stage_em = nullptr;
     *out = h;
     return STM_OK;
 }
@@ -296,6 +301,7 @@ void stm_destroy(stm_handle *h) {
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu); dfree(h->d_prof);
     dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack); dfree(h->d_ascratch); dfree(h->d_small);
     if (h->stage) (void)hipHostFree(h->stage);
+    if (h->stage_em) (void)hipHostFree(h->stage_em);
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -523,7 +529,11 @@ int stm_get_diagnostics(stm_handle *h, int32_t *status, int32_t *nit, int32_t *n
     return STM_OK;
 }
 
-int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *bound_total) {
+}  // extern "C"
+
+// Everything of one E-step enqueued on the handle's stream, no wait.  em_stage: siginv goes through the EM iteration's own
+// pinned region (the caller guarantees the previous use of it has completed).
+static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentropy, bool em_stage) {
     NEED_MODEL(h);
     if (!h->beta_set) return fail(STM_ERR_INVALID, "stm_estep: beta has not been set");
     if (!siginv) return fail(STM_ERR_INVALID, "stm_estep: siginv is NULL");
@@ -539,7 +549,11 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
         sig_bound = std::max(sig_bound, r);
     }
     const size_t KV = (size_t)h->A * K * h->V;
-    if (h->stage && sizeof(double) * (size_t)n * n <= stm_handle::STAGE_BYTES / 2) {   // second half of the staging buffer
+    if (em_stage && h->stage_em && sizeof(double) * (size_t)n * n <= stm_handle::EM_SIG) {
+        double *st = (double *)((char *)h->stage_em + stm_handle::EM_BACK);
+        memcpy(st, siginv, sizeof(double) * (size_t)n * n);
+        HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+    } else if (h->stage && sizeof(double) * (size_t)n * n <= stm_handle::STAGE_BYTES / 2) {   // second half of the staging buffer
         double *st = (double *)((char *)h->stage + stm_handle::STAGE_BYTES / 2);
         memcpy(st, siginv, sizeof(double) * (size_t)n * n);
         HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
@@ -642,20 +656,32 @@ int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *
     hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
-    double tot = 0.0;
-    int32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(&tot, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    return STM_OK;
+}
+
+// after the stream has been waited for: kernel times and the device error flag of the last E-step
+static int estep_check(stm_handle *h, int32_t err) {
     HIP_TRY(hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[1]));
     HIP_TRY(hipEventElapsedTime(&h->ms[1], h->ev[1], h->ev[2]));
     HIP_TRY(hipEventElapsedTime(&h->ms[2], h->ev[0], h->ev[3]));
-    if (bound_total) *bound_total = tot;
     if (err == STM_ERR_BETA) return fail(STM_ERR_BETA, "Some entries of beta are negative or nan.");
     if (err == STM_ERR_PHI) return fail(STM_ERR_PHI, "Some values of phi are zero or nan.");
     if (err == STM_ERR_LINALG) return fail(STM_ERR_LINALG, "Cholesky decomposition of the Hessian failed after every fallback");
     if (err) return fail(STM_ERR_INVALID, "device error flag " + std::to_string(err));
     return STM_OK;
+}
+
+extern "C" {
+
+int stm_estep(stm_handle *h, const double *siginv, double sigmaentropy, double *bound_total) {
+    if (int rc = estep_enqueue(h, siginv, sigmaentropy, false)) return rc;
+    double tot = 0.0;
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&tot, h->d_scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bound_total) *bound_total = tot;
+    return estep_check(h, err);
 }
 
 int stm_get_phi(stm_handle *h, int64_t doc, double *phi) {

@@ -262,6 +262,7 @@ def init_from_env(timeout=600.0):
 class SingleComm:
     """world_size 1: nothing to exchange."""
     rank, size, kind = 0, 1, "single"
+    device_collective = True     # nothing to exchange: the engine's fused iteration applies
 
     def attach(self, engine):
         pass
@@ -324,6 +325,7 @@ class HostComm(_GroupComm):
 class RcclComm(_GroupComm):
     """RCCL all-reduce of the device-resident sufficient statistics (one per EM iteration)."""
     kind = "rccl"
+    device_collective = True     # stm_em_begin all-reduces the packed buffer on the device
 
     def attach(self, engine):
         uid = self.group.broadcast(engine.comm_unique_id() if self.rank == 0 else None, src=0)

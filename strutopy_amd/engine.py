@@ -181,6 +181,24 @@ class HipEstepEngine:
     def update_beta(self):
         check(self._L.stm_mstep_update_beta(self._h))
 
+    # -- the whole iteration with one host wait ------------------------------------------------
+    def em_begin(self, siginv, sigmaentropy, p):
+        """E-step + moments (+ all-reduce with a communicator attached), one wait: (bound, sigma_ss, moments)."""
+        n = self.K - 1
+        siginv = f64(siginv).reshape(n, n)
+        tot = C.c_double(0.0)
+        sig = np.empty((n, n))
+        mom = np.empty(1 + p + n + p * p + p * n + n * n)
+        check(self._L.stm_em_begin(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot), dptr(sig), dptr(mom), len(mom)))
+        self.last_bound = tot.value
+        return tot.value, sig, mom
+
+    def em_finish(self, gamma=None, mean_eta=None):
+        """mu and beta of the M-step, enqueued behind the E-step (no wait)."""
+        g = None if gamma is None else f64(gamma)
+        m = None if mean_eta is None else f64(mean_eta)
+        check(self._L.stm_em_finish(self._h, dptr(g) if g is not None else None, dptr(m) if m is not None else None))
+
     # -- held-out likelihood ---------------------------------------------------------------
     def eval_heldout(self, indptr, indices, counts, theta=None):
         """Per-document held-out per-word log-likelihood against the resident beta (heldout.py:88-97)."""

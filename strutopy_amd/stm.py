@@ -366,13 +366,26 @@ class STM:
         if use_reg and not self._cov_on_device:
             eng.put_covariates(self._Xenc)      # before the E-step: a wide X re-allocates the packed buffer
             self._cov_on_device = True
-        bound_local = self._estep_device()
-        t1 = time.time()
         p = self._Xenc.shape[1] if use_reg else 0
-        mom = eng.moments(p)
-        bound, mom = self.comm.allreduce_suffstats(eng, mom)
-        if self.comm.size == 1:
-            bound = bound_local
+        # engines with device-side collectives run the iteration with ONE host wait (stm_em_begin / stm_em_finish);
+        # the host reduction (HostComm) and the test double take the call-by-call path
+        fused = getattr(self.comm, "device_collective", False) and hasattr(eng, "em_begin")
+        if fused:
+            self._preamble()
+            for name in ("beta", "eta", "mu"):
+                self._push(name)
+            bound, sigma_ss, mom = eng.em_begin(self.siginv, float(self.sigmaentropy), p)
+            self._fresh["eta"] = self._fresh["theta"] = "device"
+            self._phi_stale = True
+            t1 = time.time()
+        else:
+            bound_local = self._estep_device()
+            t1 = time.time()
+            mom = eng.moments(p)
+            bound, mom = self.comm.allreduce_suffstats(eng, mom)
+            if self.comm.size == 1:
+                bound = bound_local
+            sigma_ss = None
         self.bound = bound
         self.last_bounds.append(self.bound)
         Ntot = mom[0]
@@ -391,25 +404,32 @@ class STM:
             else:
                 coef = np.linalg.pinv(Sxx, rcond=1e-12, hermitian=True) @ Sxe  # minimum-norm OLS
             self.gamma = coef.T                                              # (K-1) x p, stm.py:703
-            eng.set_mu_regression(self.gamma)
             cov, ratio = self._covariance_from_moments(ete, Ntot, se, XtX, Xte)
+            mu_arg = dict(gamma=self.gamma)
         else:
-            eng.set_mu_constant(se / Ntot)                                   # stm.py:651
             cov, ratio = self._covariance_from_moments(ete, Ntot, se)
-        self._fresh["mu"] = "device"
-        # the expansion loses -log10(ratio) digits to cancellation; every rank sees the same reduced moments,
-        # so every rank takes the same branch
-        if self.cov_exchange == "exact" or not np.isfinite(ratio) or ratio < 1e-4:
-            cov = self.comm.allreduce_small(eng, eng.covariance())           # stm.py:723, second all-reduce
-            self.cov_exchanges.append("exact")
-        else:
-            self.cov_exchanges.append("moments")
-        sigma_ss = eng.get_sigma_ss()
-        self._finish_sigma(cov, sigma_ss, self.sigma_prior)
+            mu_arg = dict(mean_eta=se / Ntot)                                # stm.py:651
         if not self.LDAbeta:
             raise NotImplementedError("lda_beta=False (mnreg, reference stm.py:749-853) is out of scope")
-        eng.update_beta()                                                    # stm.py:741-745
+        # the expansion loses -log10(ratio) digits to cancellation; every rank sees the same reduced moments,
+        # so every rank takes the same branch
+        exact = self.cov_exchange == "exact" or not np.isfinite(ratio) or ratio < 1e-4
+        if fused and not exact:
+            eng.em_finish(**mu_arg)                                          # mu, beta: enqueued, no wait
+        else:
+            if use_reg:
+                eng.set_mu_regression(self.gamma)
+            else:
+                eng.set_mu_constant(mu_arg["mean_eta"])
+            if exact:
+                cov = self.comm.allreduce_small(eng, eng.covariance())       # stm.py:723, second all-reduce
+            eng.update_beta()                                                # stm.py:741-745
+        self.cov_exchanges.append("exact" if exact else "moments")
+        self._fresh["mu"] = "device"
         self._fresh["beta"] = "device"
+        if sigma_ss is None:
+            sigma_ss = eng.get_sigma_ss()
+        self._finish_sigma(cov, sigma_ss, self.sigma_prior)
         t2 = time.time()
         self.timings.append(dict(estep=t1 - t0, mstep=t2 - t1, kernels=eng.kernel_ms()))
 
