@@ -120,6 +120,7 @@ struct stm_handle {
     int nw = 1;                  // wavefronts per document in the solver
     int KP = 0;                  // slab row length (doubles)
     int vpl = 1;                 // vector components per lane in the solver (2 for 64 < K <= 128)
+    bool direct = false;         // K > 64: rows re-gathered from betaT per pass instead of a per-document slab
     // optional dumps
     double *d_phi = nullptr;
     int64_t phi_doc = -1;
@@ -163,7 +164,8 @@ using SolverFn = void (*)(stm::SolverParams);
 
 // solver instantiations: KREG topics of the register-resident words (0: none), LDS or global slab,
 // one or two wavefronts per document
-static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1) {
+static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, bool direct = false) {
+    if (vpl == 2 && direct) return stm::solver_kernel<2, 0, false, 1, 1>;   // 64 < K <= 128, rows re-gathered per pass
     if (vpl == 2) return global_slab ? stm::solver_kernel<2, 0, true> : stm::solver_kernel<2, 0, false>;   // 64 < K <= 128
     if (global_slab) return stm::solver_kernel<1, 0, true>;
     if (nw == 2) {
@@ -206,10 +208,16 @@ static int plan_solver(stm_handle *h) {
     const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
     h->KP = KP;
     const size_t h_lds = h->nw == 2 ? (size_t)h->n * h->n * sizeof(double) : 0;  // BFGS matrix in LDS (two-wave form)
-    auto lds_of = [&](int nd) { return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double) + h_lds; };
+    // K > 64 (STM_SOLVER_K100 = "direct" unless set to 0): no copy of beta_d, one 16-word LDS tile re-gathered from betaT per pass
+    h->direct = h->vpl == 2 && mode == 0 && env_int("STM_SOLVER_K100_DIRECT", 1) != 0;
+    auto lds_of = [&](int nd) {
+        if (h->direct) return (size_t)16 * KP * sizeof(double) + (size_t)nd * (2 * sizeof(double) + sizeof(int32_t)) + 16;
+        return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double) + h_lds;
+    };
     auto per_cu = [&](int nd) -> int {
         const size_t b = ((lds_of(nd) + LDS_STATIC + 511) / 512) * 512;
         if (mode == 2 || b > LDS_PER_CU) return 0;
+        if (h->direct) return (int)std::min<size_t>((size_t)cmax, LDS_PER_CU / b);
         // K > 64: one wave per document and nothing to hide its latencies but other documents -- below four
         // documents per CU the HBM slab (occupancy bound by registers only) wins (C4: 93 / 25 / 43 -> 54 / 24 / 27 ms)
         if (h->vpl == 2 && mode == 0 && LDS_PER_CU / b < 4) return 0;
@@ -239,7 +247,7 @@ static int plan_solver(stm_handle *h) {
         i = j;
     }
     if (max_dyn > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw, h->vpl),
+        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw, h->vpl, h->direct),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn);
         if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
@@ -596,7 +604,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
-            const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl);
+            const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl, h->direct);
             const unsigned bdim = gr.global ? 64u : 64u * (unsigned)h->nw;
             sp.ld = gr.ld;
             sp.lds_doubles = (int)(gr.lds_bytes / sizeof(double));

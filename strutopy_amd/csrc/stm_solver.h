@@ -200,13 +200,20 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
 // and the prior's quadratic form (while wave 0 takes max / exp) and then its share of the data term --
 // the independent pieces of one objective evaluation run on two SIMD slots at once (three barriers
 // per evaluation; everything the solver's control flow sees still passes through wave 0).
-template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1>
+// DIRECT = 1 (VPL = 2, K > 64, where beta -- 40 MB at config 4 -- is far beyond what a CU can keep of a document):
+// no private copy of beta_d at all.  Every pass over the document (column sums + g0 once, then every objective
+// evaluation) re-gathers the rows from betaT itself, 16 words at a time through one LDS tile: a row is one coalesced
+// run, rows are shared by all documents and stay in the L2 / Infinity Cache, whereas the per-document HBM slab of the
+// GLOBAL_SLAB form (120 KB per document at K = 100) is streamed from HBM once per evaluation.
+template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1, int DIRECT = 0>
 __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
     constexpr int KMAX = 64 * VPL;
     constexpr int VREG = (KREG > 0) ? WAVE * NW : 0;  // words held in registers
     constexpr int KR = (KREG > 0) ? KREG : 2;
     static_assert(KREG % 2 == 0 && KREG <= KMAX, "KREG must be even and <= 64*VPL");
     static_assert(NW == 1 || (NW == 2 && VPL == 1 && KREG > 0 && !GLOBAL_SLAB), "two-wave form: VPL = 1, registers + LDS");
+    static_assert(!DIRECT || (VPL == 2 && KREG == 0 && !GLOBAL_SLAB && NW == 1), "direct gather: the K > 64 one-wave form");
+    constexpr int TWS = 16;   // DIRECT: words per LDS tile
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld] | H[n][n] (NW = 2)
     __shared__ __attribute__((aligned(16))) double se[KMAX + 2];  // exp(eta~ - m), broadcast to every lane
     __shared__ double sv[KMAX + 1];  // vector broadcast (matvec operand / s)
@@ -221,11 +228,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     const int wv = NW == 2 ? (int)(threadIdx.x >> 6) : 0;
     const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
     double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
-    double *crow = slab + (size_t)KP * ld;  // counts of the slab words
+    // DIRECT: dyn_lds = tile[TWS][KP] | crow[ld] | wrow[ld] | sidx[ld] (int32)
+    double *crow = slab + (size_t)KP * (DIRECT ? TWS : ld);  // counts of the slab words
     // the HBM slab is topic-major (slab[k][word]: a wave's read of one topic for 64 words is one coalesced run), the LDS
     // slab word-major (slab[word][KP]: a lane streams its own row with ds_read_b128)
     auto SI = [&](int vv, int k) __attribute__((always_inline)) -> size_t { return GLOBAL_SLAB ? (size_t)k * ld + vv : (size_t)vv * KP + k; };
     double *wrow = crow + ld;               // counts / colsum(beta_d)
+    int32_t *sidx = reinterpret_cast<int32_t *>(wrow + ld);   // DIRECT: word ids of the document
     // BFGS inverse-Hessian estimate (n x n): in LDS behind the slab for the two-wave form (its slab is
     // small), in a private global slab otherwise
     double *Hs = (NW == 2) ? dyn_lds + (size_t)(KP + 2) * ld : P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
@@ -345,6 +354,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             }
             // the word counts now (the other wave waits for their sum); the column sums of the slab rows after the exchange
             for (int vv = lane; vv < NdL; vv += WAVE) csum += vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
+        } else if constexpr (DIRECT) {
+            for (int vv = lane; vv < NdL; vv += WAVE) {
+                sidx[vv] = P.indices[p0 + vv];
+                const double c = P.counts[p0 + vv];
+                crow[vv] = c;
+                csum += c;
+            }
         } else
         for (int vv = lane; vv < NdL; vv += WAVE) {
             const int idx = P.indices[p0 + VREG + vv];
@@ -419,6 +435,79 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         }
 
         const long long t_g2 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+        // ---- DIRECT: one LDS tile of TWS rows, fetched from betaT for every pass over the document.  Lane k loads
+        // components k and k + 64 of each row (two coalesced runs per row, any K), one tile ahead of its use.
+        double pre[DIRECT ? 2 * TWS : 1];
+        auto tile_fetch = [&](int t0) __attribute__((always_inline)) {
+            if constexpr (DIRECT) {
+                const int my = (t0 + lane < NdL && lane < TWS) ? sidx[t0 + lane] : 0;
+#pragma unroll
+                for (int j = 0; j < TWS; ++j) {
+                    const double *row = bT + (size_t)__builtin_amdgcn_readlane(my, j) * K;
+                    const bool in = t0 + j < NdL;   // uniform
+                    pre[2 * j] = (in && lane < K) ? row[lane] : 0.0;
+                    pre[2 * j + 1] = (in && lane + WAVE < K) ? row[lane + WAVE] : 0.0;
+                }
+            }
+        };
+        auto tile_store = [&]() __attribute__((always_inline)) {   // pre -> tile[j][lane], tile[j][lane + 64]; zeros beyond K
+            if constexpr (DIRECT) {
+#pragma unroll
+                for (int j = 0; j < TWS; ++j) {
+                    slab[(size_t)j * KP + lane] = pre[2 * j];
+                    if (lane + WAVE < KP) slab[(size_t)j * KP + lane + WAVE] = pre[2 * j + 1];
+                    if (lane + 2 * WAVE < KP) slab[(size_t)j * KP + lane + 2 * WAVE] = 0.0;   // K = 127, 128: the row's padding
+                }
+            }
+        };
+        // lane = (word lane & 15, quarter lane >> 4 of the row): the lane's share of sum_k f(k) over the row, the four
+        // quarters combined by two exchanges -- every lane of a word ends up with the word's total
+        const int dw = lane & 15, dq = lane >> 4;
+        const int kq2 = ((KP >> 1) + 3) >> 2;                       // 16-byte pieces per quarter
+        if constexpr (DIRECT) {
+            if (NdL > 0) STM_WAVE_SYNC();                            // sidx / crow visible to the wave
+            double g0a[VPL];
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) g0a[r] = 0.0;
+            tile_fetch(0);
+            for (int t0 = 0; t0 < NdL; t0 += TWS) {
+                const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
+                tile_store();
+                STM_WAVE_SYNC();
+                if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
+                // (a) column sums (np.sum(beta_d, axis=0)) and the beta >= 0 assertion (stm.py:534)
+                {
+                    const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);
+                    double c0s = 0.0, c1s = 0.0;
+                    const int k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
+                    for (int kk = dq * kq2; kk < k1; ++kk) {
+                        const double2 b = tr[kk];
+                        bad |= !(b.x >= 0.0) | !(b.y >= 0.0);
+                        c0s += b.x; c1s += b.y;
+                    }
+                    double cs = c0s + c1s;
+                    cs += __shfl_xor(cs, 16);
+                    cs += __shfl_xor(cs, 32);
+                    if (dq == 0 && dw < nw) wrow[t0 + dw] = crow[t0 + dw] / cs;
+                }
+                STM_WAVE_SYNC();
+                // (b) g0 += beta_d[:, tile] @ (c / colsum), lane = topic
+#pragma unroll 4
+                for (int w = 0; w < nw; ++w) {
+                    const double wq = wrow[t0 + w];
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r)
+                        if (lane + WAVE * r < KP) g0a[r] = fma(slab[(size_t)w * KP + lane + WAVE * r], wq, g0a[r]);
+                }
+                STM_WAVE_SYNC();
+            }
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) g0[r] = (lane + WAVE * r < n) ? g0a[r] : 0.0;
+            if (wave_any(bad)) {   // "Some entries of beta are negative or nan." (stm.py:534)
+                atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
+                return;
+            }
+        }
         // g0 = beta_d @ (c / colsum(beta_d)) -- the eta-independent data term of df (stm.py:954)
         auto g0_slab = [&](int k) __attribute__((always_inline)) -> double {
             double t = 0.0;
@@ -430,7 +519,9 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             for (int r = 0; r < VPL; ++r)
                 if (k == lane + WAVE * r) g0[r] = t;
         };
-        if (KREG > 0 && VPL == 1) {
+        if constexpr (DIRECT) {
+            // done above, tile by tile
+        } else if (KREG > 0 && VPL == 1) {
             // wave_sum()'s additions in wave_sum()'s order, but the four row totals of every topic are combined for all
             // topics at once: after the intra-row steps lane (row r, position c) keeps the row-r total of topic 16 q + c
             // in acc[q]; two cross-row exchanges per q finish the sums, and lane k picks topic k.
@@ -547,6 +638,31 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 __builtin_amdgcn_sched_barrier(0);
                 const double lg = m + log_pos(s0 + s1);
                 part = (wreg < Nd) ? c0 * lg : 0.0;
+            }
+            if constexpr (DIRECT) {   // re-gather tile by tile; lane = (word, quarter of the topics)
+                tile_fetch(0);
+                const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
+                for (int t0 = 0; t0 < NdL; t0 += TWS) {
+                    const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
+                    tile_store();
+                    STM_WAVE_SYNC();
+                    if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
+                    const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 4
+                    for (int kk = k0; kk < k1; ++kk) {
+                        const double2 e = se2[kk], b = tr[kk];
+                        a0 = fma(e.x, b.x, a0);
+                        a1 = fma(e.y, b.y, a1);
+                    }
+                    double sdot = a0 + a1;
+                    sdot += __shfl_xor(sdot, 16);
+                    sdot += __shfl_xor(sdot, 32);
+                    const double lg = m + log_pos(sdot);
+                    part += (dq == 0 && dw < nw) ? crow[t0 + dw] * lg : 0.0;
+                    STM_WAVE_SYNC();
+                }
+                return part;
             }
             // slab words: every lane streams its word's row (ds_read_b128), two 64-word tiles per
             // sweep so the broadcast se pair is read once for both
