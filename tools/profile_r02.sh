@@ -26,3 +26,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc1_${tag}_$c -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > gpurun_out/pmc1_${tag}_$c.log 2>&1
 done
 python tools/traffic_summary.py $(find gpurun_out/pmc1_${tag}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc1_${tag}_WRITE_SIZE -name "*counter_collection.csv" | head -1) gpurun_out/hbm_traffic_$tag.json | tail -12
+# config 4's per-GPU share: kernel stats of `bench.py --config c4`
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_c4 -o ${tag}_c4 --output-format csv -- python bench.py --config c4 --steps 8 --warmup 2 > gpurun_out/${tag}_c4_bench.json 2> gpurun_out/${tag}_c4_bench.err
+find gpurun_out/prof_${tag}_c4 -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_c4_kernel_stats.csv \;
+python tools/by_iteration.py trace $(find gpurun_out/prof_${tag}_c4 -name "*kernel_trace.csv" | head -1) 2 8 > gpurun_out/${tag}_c4_by_iteration.txt 2>&1
+cat gpurun_out/${tag}_c4_by_iteration.txt
