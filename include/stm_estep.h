@@ -168,6 +168,10 @@ int stm_spectral_get_q(stm_handle *h, const int32_t *rows, int32_t nrows, double
 int stm_spectral_anchors(stm_handle *h, int32_t K, int32_t *anchor /* [K] out */);
 /* the per-word QP inputs of recover_l2 (stm.py:239-270): q[i][k] = Q[i] . Q[anchor[k]]; P = q[anchor] */
 int stm_spectral_project(stm_handle *h, int32_t K, const int32_t *anchor, double *q_out /* [Vk][K] */);
+/* recover_l2's per-term QPs on the device (stm.py:257-285): weights[i] = -argmin_{x <= 0} 1/2 x'Px + q_i'x with P = q[anchor],
+ * one-hot rows for the anchor terms; the strictly convex QP is solved as the non-negative least-squares fit it is
+ * (Lawson-Hanson active set), one thread per term.  K <= 128. */
+int stm_spectral_weights(stm_handle *h, int32_t K, const int32_t *anchor, double *weights_out /* [Vk][K] */);
 int stm_spectral_release(stm_handle *h);
 
 /* ---- multi-GPU: one RCCL all-reduce of the sufficient statistics ------- */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "stm_spectral_get_q": (C.c_int, [_h, _ip, C.c_int32, _dp]),
     "stm_spectral_anchors": (C.c_int, [_h, C.c_int32, _ip]),
     "stm_spectral_project": (C.c_int, [_h, C.c_int32, _ip, _dp]),
+    "stm_spectral_weights": (C.c_int, [_h, C.c_int32, _ip, _dp]),
     "stm_spectral_release": (C.c_int, [_h]),
     "stm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "stm_comm_init": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),

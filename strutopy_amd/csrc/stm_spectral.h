@@ -7,8 +7,8 @@
 //                      run-to-run identical
 //   fastAnchor pieces  (stm.py:160-226) column sums of squares, first-maximum search, row scaling,
 //                      Q @ Q[m]^T, rank-one projection off every row outside `basis`
-//   project_kernel     q_i = M y_i for every word i (M = anchor rows; stm.py:239, :266-270): the inputs of the
-//                      per-word QP, whose K x K solves stay on the host
+//   anchor_project     q_i = M y_i for every word i (M = anchor rows; stm.py:239, :266-270): the inputs of the per-word QP
+//   nnls_kernel        the per-word QPs themselves (stm.py:271-285), one thread per word
 // All HBM-bound streaming passes over the 8 Vk^2-byte matrix (200 MB at maxV = 5000).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -140,6 +140,101 @@ __global__ __launch_bounds__(64) void anchor_project_kernel(const double *Q, int
         const double t = wave_sum(t0 + t1);
         if (lane == 0) q[(size_t)i * K + k] = t;
     }
+}
+
+// recover_l2's per-term QP (stm.py:257-285):  x = argmin 1/2 x^T P x + q_i^T x  s.t. x <= 0,  weights_i = -x, i.e. the
+// non-negative least-squares fit  w = argmin_{w >= 0} 1/2 w^T P w - q_i^T w  (P = M M^T positive definite: the minimiser is unique,
+// whatever solver finds it -- the reference calls quadprog).  Lawson-Hanson active set on the normal equations, one THREAD per
+// term (5000 small independent problems; scalar code, per-thread state in scratch, the passive-set Cholesky factor in a private
+// slice of global memory).  Anchor terms get their one-hot row (stm.py:261-264).
+constexpr int NNLS_KMAX = 128;
+__global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t *anchor, int K, int Vk, double *fac /* [Vk][K][K] */,
+                                                   double *weights /* [Vk][K] */, int32_t *iters_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Vk) return;
+    double *w_out = weights + (size_t)i * K;
+    for (int k = 0; k < K; ++k) w_out[k] = 0.0;
+    for (int k = 0; k < K; ++k)
+        if (anchor[k] == i) {              // vec[np.where(anchor == i)] = 1
+            w_out[k] = 1.0;
+            if (iters_out) iters_out[i] = 0;
+            return;
+        }
+    const double *qi = q + (size_t)i * K;
+    // P = M M^T = the rows `anchor` of q (q[a][k] = Q[a] . Q[anchor[k]])
+    auto Pm = [&](int a, int b) -> double { return q[(size_t)anchor[a] * K + b]; };
+    double w[NNLS_KMAX], z[NNLS_KMAX], rhs[NNLS_KMAX];
+    int idx[NNLS_KMAX];
+    bool inS[NNLS_KMAX];
+    double qmax = 0.0;
+    for (int k = 0; k < K; ++k) { w[k] = 0.0; inS[k] = false; qmax = fmax(qmax, fabs(qi[k])); }
+    const double tol = 1e-13 * fmax(qmax, 1e-300) * K;
+    double *L = fac + (size_t)i * K * K;    // lower triangular factor of P_SS, row-major with leading dimension K
+    int it = 0;
+    for (; it < 3 * K; ++it) {
+        // dual = q - P w over the free terms; the most violated one joins the passive set
+        int jbest = -1;
+        double dbest = tol;
+        for (int j = 0; j < K; ++j) {
+            if (inS[j]) continue;
+            double d = qi[j];
+            for (int k = 0; k < K; ++k)
+                if (inS[k]) d -= Pm(j, k) * w[k];
+            if (d > dbest) { dbest = d; jbest = j; }
+        }
+        if (jbest < 0) break;
+        inS[jbest] = true;
+        for (int inner = 0; inner < 3 * K; ++inner) {
+            int s = 0;
+            for (int k = 0; k < K; ++k)
+                if (inS[k]) idx[s++] = k;
+            // Cholesky of P_SS, then L y = q_S, L^T z = y
+            bool ok = true;
+            for (int a = 0; a < s && ok; ++a) {
+                for (int b = 0; b <= a; ++b) {
+                    double t = Pm(idx[a], idx[b]);
+                    for (int c = 0; c < b; ++c) t -= L[a * K + c] * L[b * K + c];
+                    if (a == b) {
+                        if (!(t > 0.0)) { ok = false; break; }
+                        L[a * K + a] = sqrt(t);
+                    } else {
+                        L[a * K + b] = t / L[b * K + b];
+                    }
+                }
+            }
+            if (!ok) { inS[jbest] = false; w[jbest] = 0.0; break; }   // numerically dependent column: leave it out
+            for (int a = 0; a < s; ++a) {
+                double t = qi[idx[a]];
+                for (int c = 0; c < a; ++c) t -= L[a * K + c] * rhs[c];
+                rhs[a] = t / L[a * K + a];
+            }
+            for (int a = s - 1; a >= 0; --a) {
+                double t = rhs[a];
+                for (int c = a + 1; c < s; ++c) t -= L[c * K + a] * z[c];
+                z[a] = t / L[a * K + a];
+            }
+            bool allpos = true;
+            for (int a = 0; a < s; ++a) allpos = allpos && (z[a] > 0.0);
+            if (allpos) {
+                for (int a = 0; a < s; ++a) w[idx[a]] = z[a];
+                break;
+            }
+            double alpha = 1.0;
+            for (int a = 0; a < s; ++a)
+                if (!(z[a] > 0.0)) {
+                    const double wa = w[idx[a]];
+                    const double r = wa / (wa - z[a]);
+                    if (r < alpha) alpha = r;
+                }
+            for (int a = 0; a < s; ++a) {
+                const int k = idx[a];
+                w[k] += alpha * (z[a] - w[k]);
+                if (!(w[k] > tol * 1e-3)) { w[k] = 0.0; inS[k] = false; }
+            }
+        }
+    }
+    for (int k = 0; k < K; ++k) w_out[k] = w[k];
+    if (iters_out) iters_out[i] = it;
 }
 
 }  // namespace stm

@@ -236,6 +236,12 @@ class HipEstepEngine:
         check(self._L.stm_spectral_project(self._h, len(anchor), iptr(anchor), dptr(out)))
         return out
 
+    def spectral_weights(self, anchor):
+        anchor = np.ascontiguousarray(anchor, dtype=np.int32)
+        out = np.empty((self._Vk, len(anchor)))
+        check(self._L.stm_spectral_weights(self._h, len(anchor), iptr(anchor), dptr(out)))
+        return out
+
     def spectral_release(self):
         check(self._L.stm_spectral_release(self._h))
 

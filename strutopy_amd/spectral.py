@@ -5,13 +5,13 @@ Same statements as the reference, with the V x V work on the GPU behind the C-AB
   word probabilities, the maxV most frequent terms      host (np.argsort(-wprob), stm.py:50-58)
   gram: Q = Htilde^T Htilde - diag(Hhat)                 stm_spectral_gram     (stm.py:122-157)
   fastAnchor: greedy anchor terms                        stm_spectral_anchors  (stm.py:160-226)
-  recover_l2: q_i = M y_i for every term, P = M M^T       stm_spectral_project  (stm.py:239, 266-270)
-              per-term QP  min 1/2 x'Px + q'x, x <= 0     host, K x K (stm.py:271-285)
+  recover_l2: q_i = M y_i for every term, P = M M^T,      stm_spectral_weights  (stm.py:239, 257-285)
+              per-term QP  min 1/2 x'Px + q'x, x <= 0
   beta[:, keep], + 0.001 / V, / total sum                 host (stm.py:78-83)
 
 The reference hands the per-term QP to qpsolvers/quadprog.  It is the strictly convex non-negative least-squares
-problem min || M^T w - y ||, w >= 0 (w = -x), whose minimiser does not depend on the solver; it is solved here with
-scipy.optimize.nnls on the Cholesky factor of P.  Quirks of the reference that are kept: Q is NOT row-normalised
+problem min || M^T w - y ||, w >= 0 (w = -x), whose minimiser does not depend on the solver; it is solved on the device
+by a Lawson-Hanson active set, one thread per term (`solve_weights` below -- SciPy's nnls -- is what the tests check it against).  Quirks of the reference that are kept: Q is NOT row-normalised
 (sklearn's normalize(copy=False) works on a discarded CSR copy of the CSC product), fastAnchor uses column sums of
 squares and never projects row 0, the first anchor's row of the caller's Q is rescaled, no sum-to-one constraint,
 and the final division by the TOTAL sum leaves every row of beta summing to 1 / K.
@@ -88,14 +88,16 @@ def spectral_init(corpus, K, V, maxV=5000, verbose=True, engine=None, details=No
         anchor = engine.spectral_anchors(K)
         if verbose:
             print("Recover values for beta")
-        q = engine.spectral_project(anchor)
+        if hasattr(engine, "spectral_weights"):
+            weights = engine.spectral_weights(anchor)          # q_i = M y_i and the per-term QPs, on the device
+        else:                                                    # engines without it (the CPU test double): SciPy
+            weights = solve_weights(engine.spectral_project(anchor), anchor)
         if details is not None:
-            details.update(wprob=wprob, keep=keep, anchor=anchor.astype(np.float64), q=q, engine=engine if not own else None)
+            details.update(wprob=wprob, keep=keep, anchor=anchor.astype(np.float64), weights=weights)
         engine.spectral_release()
     finally:
         if own:
             engine.close()
-    weights = solve_weights(q, anchor)
     A = weights.T * wprob                                                # p(w|z) = p(z|w) p(w), stm.py:290
     A = A.T / np.sum(A, axis=1)
     assert np.any(A > 0), "Negative probabilities for some words."

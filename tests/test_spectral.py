@@ -114,6 +114,16 @@ def test_device_gram_anchors_and_beta_match_the_reference(name):
     _check_parts(g, keep, wprob, anchor, q_rows)
     if "Q_caller_anchor_rows" in g.files:
         assert np.allclose(e.spectral_q_rows(anchor), g["Q_caller_anchor_rows"], rtol=1e-12, atol=1e-15)
+    # the per-term QPs on the device against SciPy's NNLS on the same inputs (and the KKT conditions of the QP)
+    from strutopy_amd.spectral import solve_weights
+    q = e.spectral_project(anchor)
+    w_dev, w_ref = e.spectral_weights(anchor), solve_weights(q, anchor)
+    assert w_dev.min() >= 0 and np.allclose(w_dev, w_ref, rtol=1e-8, atol=1e-10 * np.abs(w_ref).max())
+    P = q[np.intp(anchor)]
+    grad = w_dev @ P - q
+    free = np.ones(len(q), dtype=bool); free[np.intp(anchor)] = False
+    scale = np.abs(q).max()
+    assert grad[free].min() >= -1e-9 * scale and np.abs(grad[free][w_dev[free] > 0]).max() <= 1e-9 * scale
     e.spectral_release()
     det = {}
     beta = spectral_init(c, K, V, verbose=False, engine=e, details=det)
