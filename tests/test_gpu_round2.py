@@ -105,6 +105,54 @@ def test_k50_later_iterations_teacher_forced(oracle, monkeypatch, flags):
             assert np.max(np.abs(d["eta"] - o["eta"])) <= 1e-7
 
 
+def _against_reference(d, g, p, tag):
+    for k in ("status", "nit", "pd_path"):
+        assert np.array_equal(d[k], g[p + k]), f"{tag}: {k} differs in {np.sum(d[k] != g[p + k])} documents"
+    assert np.max(np.abs(d["eta"] - g[p + "eta"])) <= 1e-7, tag
+    assert np.max(np.abs(d["bound_doc"] - g[p + "bound_doc"]) / np.abs(g[p + "bound_doc"])) <= 1e-8, tag
+    assert abs(d["bound"] - float(g[p + "bound"])) <= 1e-10 * abs(float(g[p + "bound"])), tag
+    assert _rel(d["sigma_ss"], g[p + "sigma_ss"]) <= 1e-8, tag
+    assert _rel(d["beta_ss"].sum(axis=-1), g[p + "beta_ss_rowsum"]) <= 1e-9, tag
+    assert _rel(d["beta_ss"].sum(axis=-2), g[p + "beta_ss_colsum"]) <= 1e-9, tag
+
+
+def test_k100_kernels_against_the_reference_itself():
+    """K = 100 (two topics per lane: solver_kernel<2,0,false,1,1> re-gathering beta rows per pass, post_big_kernel<7>) against
+    three EM iterations of the REFERENCE (tests/golden/k100_v5k.npz), teacher-forced."""
+    from strutopy_amd.engine import estep_host
+    g = load_golden("k100_v5k")
+    for it in range(3):
+        p = f"it{it}_"
+        beta = reference_beta0(100, int(g["V"])) if it == 0 else g[p + "beta_in"]
+        d = estep_host(g["indptr"], g["indices"], g["counts"], beta, g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                       float(g[p + "sigmaentropy"]))
+        _against_reference(d, g, p, f"k100 it{it}")
+
+
+def test_content_covariate_at_k50_against_the_reference_itself():
+    """BASELINE config 4's shape (K = 50, A = 2) against the reference: E-steps teacher-forced, then the resident loop's
+    device M-step for per-level beta (beta_normalise_topics_kernel) against the reference's M-step results."""
+    from strutopy_amd import STM
+    from strutopy_amd.engine import estep_host
+    g = load_golden("content_k50")
+    b0 = np.repeat(reference_beta0(50, int(g["V"]))[None], 2, axis=0)
+    for it in range(2):
+        p = f"it{it}_"
+        beta = b0 if it == 0 else g[p + "beta_in"]
+        d = estep_host(g["indptr"], g["indices"], g["counts"], beta, g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                       float(g[p + "sigmaentropy"]), aspect=g["aspect"])
+        _against_reference(d, g, p, f"content k50 it{it}")
+    m = STM(documents=_corpus(g), dictionary=None, content=True, K=50, X=g["X"][:, 0], kappa_interactions=True, A=2,
+            beta_index=g["aspect"], max_em_iter=2, sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    m.expectation_maximization(saving=False)
+    assert m.last_bounds[0] == pytest.approx(float(g["it0_bound"]), rel=1e-10)
+    assert m.last_bounds[1] == pytest.approx(float(g["it1_bound"]), rel=1e-8)
+    assert np.allclose(m.sigma, g["it1_sigma_out"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(m.beta.sum(axis=-2), g["it1_beta_out_colsum"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(m.beta.sum(axis=-1), g["it1_beta_out_rowsum"], rtol=1e-6, atol=1e-12)
+    m.close()
+
+
 # ------------------------------------------------------------------ C4's per-GPU share
 def test_config4_share_invariants_and_oracle_sample(oracle):
     """BASELINE configs[3] per GPU: 125k documents, V=50k, K=100 (beta = 40 MB, beyond the L2): size-independent

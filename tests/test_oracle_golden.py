@@ -83,6 +83,40 @@ def test_k50_later_iterations_teacher_forced(oracle):
     assert moved > 2000          # it 4: 41 %, it 5: 100 %, it 8: 116 % BFGS iterations per document
 
 
+def _teacher_forced(g, its, beta0, aspect=None):
+    for it in range(its):
+        p = f"it{it}_"
+        beta = beta0 if it == 0 else g[p + "beta_in"]
+        yield it, p, (g["indptr"], g["indices"], g["counts"], beta, g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                      float(g[p + "sigmaentropy"]))
+
+
+def _check_against_reference(o, g, p, tag):
+    for k in ("status", "nit", "pd_path"):
+        assert np.array_equal(o[k], g[p + k]), f"{tag}: {k}"
+    assert np.max(np.abs(o["eta"] - g[p + "eta"])) <= 1e-7, tag
+    assert np.max(np.abs(o["bound_doc"] - g[p + "bound_doc"]) / np.abs(g[p + "bound_doc"])) <= 1e-9, tag
+    assert abs(o["bound"] - float(g[p + "bound"])) <= 1e-10 * abs(float(g[p + "bound"])), tag
+    assert _rel(o["sigma_ss"], g[p + "sigma_ss"]) <= 1e-8, tag
+    assert _rel(o["beta_ss"].sum(axis=-1), g[p + "beta_ss_rowsum"]) <= 1e-9, tag
+    assert _rel(o["beta_ss"].sum(axis=-2), g[p + "beta_ss_colsum"]) <= 1e-8, tag
+
+
+def test_k100_against_the_reference(oracle):
+    """tests/golden/k100_v5k.npz: K = 100 (BASELINE config 3's topic count) run by the reference itself, EM iterations 0-2."""
+    g = load_golden("k100_v5k")
+    for it, p, args in _teacher_forced(g, 3, reference_beta0(100, int(g["V"]))):
+        _check_against_reference(oracle.estep(*args, nthreads=0), g, p, f"k100 it{it}")
+
+
+def test_content_covariate_at_k50_against_the_reference(oracle):
+    """tests/golden/content_k50.npz: BASELINE config 4's shape (K = 50, A = 2 levels of beta) run by the reference."""
+    g = load_golden("content_k50")
+    b0 = reference_beta0(50, int(g["V"]))
+    for it, p, args in _teacher_forced(g, 2, np.repeat(b0[None], 2, axis=0)):
+        _check_against_reference(oracle.estep(*args, aspect=g["aspect"], nthreads=0), g, p, f"content k50 it{it}")
+
+
 def test_wiki_known_answer_shipped_by_reference(oracle):
     """ELBO[0] of src/artifacts/reference_model/50/lower_bound.pickle: the one number the
     reference itself ships for this path."""

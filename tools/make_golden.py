@@ -529,9 +529,71 @@ def case_spectral_wiki():
          qp_solver=np.asarray("tools/refshim qpsolvers stand-in (scipy nnls)"))
 
 
+def case_k100_v5k():
+    """BASELINE config 3's K = 100 against the reference itself (the other K > 64 checks are oracle-only): 400 documents,
+    V = 5000, EM iterations 0-2 with the input state of each (beta of iterations 1-2 stored: teacher-forced)."""
+    K = 100
+    c = _synthetic(K, 5000, 400, 100100)
+    docs = c.documents
+    m = make_model(docs, c.dictionary, K, c.metadata, max_em_iter=3)
+    out = {}
+    for it in range(3):
+        m._rec_reset()
+        p = f"it{it}_"
+        if it > 0:
+            out[p + "beta_in"] = np.asarray(m.beta).copy()
+        out[p + "eta_in"], out[p + "mu_in"] = m.eta.copy(), m.mu.copy()
+        beta_ss, sigma_ss = m.E_step()
+        out[p + "siginv"], out[p + "sigmaentropy"] = np.asarray(m.siginv), np.float64(m.sigmaentropy)
+        out[p + "eta"], out[p + "theta"] = m.eta.copy(), m.theta.copy()
+        out[p + "bound"], out[p + "bound_doc"] = np.float64(m.bound), np.asarray(m.rec["bound"])
+        for k in ("status", "nit", "nfev", "njev", "pd_path"):
+            out[p + k] = np.asarray(m.rec[k], dtype=np.int32)
+        out[p + "sigma_ss"] = sigma_ss.copy()
+        out[p + "beta_ss_rowsum"], out[p + "beta_ss_colsum"] = beta_ss.sum(axis=-1), beta_ss.sum(axis=-2)
+        m.M_step(beta_ss, sigma_ss)
+        print(f"    it{it}: bound={m.bound!r} nit_mean={np.mean(m.rec['nit']):.3f} pd_path={np.bincount(m.rec['pd_path'], minlength=3)}")
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("k100_v5k", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(c.metadata, dtype=np.float64),
+         K=np.int32(K), V=np.int32(len(c.dictionary)), **out)
+
+
+def case_content_k50():
+    """BASELINE config 4's shape (K = 50, content covariate with A = 2 levels of beta) against the reference: 300 documents,
+    V = 4000, two EM iterations incl. the reference's axis-1 normalisation of the 3-D beta_ss (stm.py:741)."""
+    K, A = 50, 2
+    c = _synthetic(K, 4000, 300, 50502)
+    docs = c.documents
+    bidx = np.random.default_rng(11).integers(0, A, size=len(docs))
+    m = make_model(docs, c.dictionary, K, c.metadata, content=True, interactions=True, beta_index=bidx, A=A, max_em_iter=2)
+    out = {}
+    for it in range(2):
+        m._rec_reset()
+        p = f"it{it}_"
+        if it > 0:
+            out[p + "beta_in"] = np.asarray(m.beta).copy()
+        out[p + "eta_in"], out[p + "mu_in"] = m.eta.copy(), m.mu.copy()
+        beta_ss, sigma_ss = m.E_step()
+        out[p + "siginv"], out[p + "sigmaentropy"] = np.asarray(m.siginv), np.float64(m.sigmaentropy)
+        out[p + "eta"] = m.eta.copy()
+        out[p + "bound"], out[p + "bound_doc"] = np.float64(m.bound), np.asarray(m.rec["bound"])
+        for k in ("status", "nit", "pd_path"):
+            out[p + k] = np.asarray(m.rec[k], dtype=np.int32)
+        out[p + "sigma_ss"] = sigma_ss.copy()
+        out[p + "beta_ss_rowsum"], out[p + "beta_ss_colsum"] = beta_ss.sum(axis=-1), beta_ss.sum(axis=-2)
+        m.M_step(beta_ss, sigma_ss)
+        out[p + "sigma_out"] = m.sigma.copy()
+        out[p + "beta_out_colsum"] = np.asarray(m.beta).sum(axis=-2)
+        out[p + "beta_out_rowsum"] = np.asarray(m.beta).sum(axis=-1)
+        print(f"    it{it}: bound={m.bound!r} nit_mean={np.mean(m.rec['nit']):.3f}")
+    indptr, idx, cnt = docs_to_csr(docs)
+    save("content_k50", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(c.metadata, dtype=np.float64), K=np.int32(K),
+         V=np.int32(len(c.dictionary)), A=np.int32(A), aspect=bidx.astype(np.int32), **out)
+
+
 CASES = dict(toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
-             wiki_k50=case_wiki_k50, k50_late=case_k50_late, spectral_c1=case_spectral_c1,
+             wiki_k50=case_wiki_k50, k50_late=case_k50_late, spectral_c1=case_spectral_c1, k100_v5k=case_k100_v5k, content_k50=case_content_k50,
              spectral_wiki=case_spectral_wiki)
 
 if __name__ == "__main__":
