@@ -967,9 +967,12 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             const double tr = b * prange;
             const double U = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
             const double slope0 = -derphi0;
-            const double margin = (phi_b - phi0) / b + c1 * slope0 - 0.5 * U * b;
-            const double s_lo = 0.05 * slope0 / U;
-            return slope0 > 0.0 && margin > 0.0 && s_lo * margin >= 1e-9 * py_max2(1.0, fabs((double)phi0));
+            // margin = (phi_b - phi0) / b + c1 slope0 - U b / 2 and s_lo = 0.05 slope0 / U, both multiplied through by b > 0 and U > 0:
+            // two IEEE divisions less on the state machine's dependency chain (the inequalities are sufficient conditions with a
+            // 1e-9 margin, so their last-bit rounding is immaterial)
+            const double margin_b = (phi_b - phi0) + b * (c1 * slope0 - 0.5 * U * b);
+            return slope0 > 0.0 && b > 0.0 && U > 0.0 && margin_b > 0.0 &&
+                   0.05 * slope0 * margin_b >= 1e-9 * py_max2(1.0, fabs((double)phi0)) * (U * b);
         };
 
         if (P.debug_flags & 1) st = S_FINISH;
