@@ -153,6 +153,22 @@ def test_content_covariate_at_k50_against_the_reference_itself():
     m.close()
 
 
+def test_k100_rejects_bad_beta_like_the_reference():
+    """assert np.all(beta_doc_kv >= 0) (stm.py:534) in the K > 64 solver, which checks the rows while it re-gathers them."""
+    from strutopy_amd.engine import estep_host
+    g = load_golden("k100_v5k")
+    beta = reference_beta0(100, int(g["V"])).copy()
+    args = [g["indptr"], g["indices"], g["counts"], beta, g["it0_mu_in"], g["it0_eta_in"], g["it0_siginv"], float(g["it0_sigmaentropy"])]
+    w = int(g["indices"][int(g["indptr"][7]) + 3])          # a word of document 7
+    for bad, k in ((-1e-12, 99), (np.nan, 3), (-0.5, 70)):
+        args[3] = beta.copy()
+        args[3][k, w] = bad
+        with pytest.raises(AssertionError):
+            estep_host(*args)
+    args[3] = beta
+    estep_host(*args)                                        # and the clean input still runs
+
+
 # ------------------------------------------------------------------ C4's per-GPU share
 def test_config4_share_invariants_and_oracle_sample(oracle):
     """BASELINE configs[3] per GPU: 125k documents, V=50k, K=100 (beta = 40 MB, beyond the L2): size-independent
