@@ -530,8 +530,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             // straight-line code for all KREG topics (rows K.. of the registers are zeros, topic K-1 is computed and dropped),
             // so that the KREG reduction chains interleave; three forms of the slab term: none (this wave owns no slab
             // words), one word per lane (at most 64 slab words), the general strided loop
-            const double wl = (NdL > 0 && NdL <= WAVE && lane < NdL) ? wrow[lane] : 0.0;
-            const int srow_w = (NdL <= WAVE && lane < NdL) ? lane : 0;
+            const double wl = (lane < NdL) ? wrow[lane] : 0.0;      // the lane's slab word among the first 64
+            const int srow_w = (lane < NdL) ? lane : 0;
             auto chains = [&](auto mode) __attribute__((always_inline)) {
 #pragma unroll
                 for (int k = 0; k < KR; ++k) {
@@ -545,9 +545,12 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     if ((k & 15) == c16) accq[k >> 4] = v;
                 }
             };
-            if (NdL == 0) chains(std::integral_constant<int, 0>());
-            else if (NdL <= WAVE) chains(std::integral_constant<int, 1>());
-            else chains(std::integral_constant<int, 2>());
+            // ONE instantiation of the 50 chains (each mode is ~7 KB of straight-line code, and the kernel has to share a
+            // 64 KB instruction cache with the waves of two CUs): wave 0 owns no slab words (mode 0); the last wave adds its
+            // first 64 slab words inside the chains (mode 1) and any further ones (documents beyond 192 words) in the
+            // rolled loop below
+            if (NW == 2 && wv == 0) chains(std::integral_constant<int, 0>());
+            else chains(std::integral_constant<int, 1>());
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (q * 16 < KR) {
@@ -558,6 +561,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 }
             const int q = lane >> 4;
             g0[0] = (lane < n) ? (q == 0 ? accq[0] : q == 1 ? accq[1] : q == 2 ? accq[2] : accq[3]) : 0.0;
+            if (NdL > WAVE)   // slab words beyond the first 64 (uniform; rare): one rolled loop over the topics
+                for (int k = 0; k < n; ++k) {
+                    double t = 0.0;
+                    for (int vv = lane + WAVE; vv < NdL; vv += WAVE) t += slab[SI(vv, k)] * wrow[vv];
+                    t = wave_sum(t);
+                    if (lane == k) g0[0] += t;
+                }
         } else if (KREG > 0) {
 #pragma unroll
             for (int k = 0; k < KR; ++k)
