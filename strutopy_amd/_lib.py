@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstm_hip.so")
+LIB_PATH = os.environ.get("STM_LIB_PATH") or os.path.join(_HERE, "libstm_hip.so")   # STM_LIB_PATH: A/B builds of the same source
 
 STM_OK = 0
 STM_ERR_INVALID, STM_ERR_BETA, STM_ERR_LINALG, STM_ERR_HIP = 1, 2, 3, 4
