@@ -22,11 +22,16 @@ inline int post_big_mld(int n) { return 16 * ((n + 15) / 16) + 1; }   // (PostPa
 // column updates of the Cholesky, make_pd and the dumps) lives in a per-workgroup HBM scratch.  45 KB instead of 124 KB
 // at K = 100: three workgroups per CU.  Only the n real rows exist: row indices are clamped on reads, masked on writes.
 __host__ __device__ inline int post_big_row(int i) { return (i * (i + 1)) >> 1; }
-__host__ __device__ inline int post_big_tri(int n) { return post_big_row(n) + 16 + WAVE; }   // + slack + dump cells
-__host__ __device__ inline int post_big_reg0(int n) { const int tri = post_big_tri(n), tile = BT * TLD; return ((tri > tile ? tri : tile) + 1) & ~1; }
-inline size_t post_big_lds_doubles(int n) {
-    return (size_t)post_big_reg0(n) + 4 * BT + 4 * TW;   // the word tile aliases the matrix (word loop only)
+__host__ __device__ inline int post_big_nv(int n) { const int v = ((n + 1 + 7) >> 3) << 3; return v < BT ? v : BT; }   // per-topic LDS vector: K rounded up to 8
+__host__ __device__ inline int post_big_tri(int n) { return post_big_row(n) + 16 + 1; }   // + slack (block reads past the last row) + one dump cell
+// region 0: the matrix, or -- during the word loop -- the tile, the per-word pack and exp(eta~)
+__host__ __device__ inline int post_big_reg0(int n) {
+    const int tri = post_big_tri(n), tile = BT * TLD + 4 * TW + post_big_nv(n);
+    return ((tri > tile ? tri : tile) + 1) & ~1;
 }
+// + ONE per-topic vector whose content changes with the phase (theta -> diagonal of A -> eta - mu -> 1 / diag(L)):
+// 40.6 KB at K = 100, i.e. FOUR workgroups per CU -- one per SIMD (three with the 44.8 KB of separate vectors)
+inline size_t post_big_lds_doubles(int n) { return (size_t)post_big_reg0(n) + post_big_nv(n); }
 
 template <int NB>   // NB = ceil((K-1) / 16) block rows: 4 .. 8
 __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
@@ -34,16 +39,17 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
     int lane = threadIdx.x;
     const int K = P.K, n = P.n;
     constexpr int MROWS = 16 * NB;
-    const int MDUMP = post_big_row(n) + 16, REG0 = post_big_reg0(n);
+    const int MDUMP = post_big_row(n) + 16, REG0 = post_big_reg0(n), NV = post_big_nv(n);
     double *M = big_lds;                        // row-packed lower triangle (post_big_row): L, then X = L^-1
     double *T = big_lds;                        // [BT][TLD] word tile, topic-major (16-byte aligned rows); word loop only
-    double *sex = big_lds + REG0;               // exp(eta~)
+    double *wpar = big_lds + BT * TLD;          // word loop: per word of the tile { sqrt(c), S, 1/S, sqrt(c)/S }, behind the tile
+    double *sex = wpar + 4 * TW;                // word loop: exp(eta~), behind the pack (all inside region 0: M is not live then)
+    double *vec = big_lds + REG0;               // the one per-topic vector outside region 0
     double *Ag = P.a_scratch + (size_t)blockIdx.x * (size_t)n * n;   // A, upper triangle (row-major n x n), HBM scratch
     auto RS = [](int i) __attribute__((always_inline)) { return post_big_row(i); };
-    double *sth = sex + BT;                     // stable_softmax(eta~)
-    double *sdv = sth + BT;                     // eta - mu (dense siginv only)
-    double *srd = sdv + BT;                     // 1 / diag(L)
-    double *wpar = srd + BT;                    // per word of the tile: { sqrt(c), S, 1/S, sqrt(c)/S }
+    double *sth = vec;                          // word loop + assembly: stable_softmax(eta~)
+    double *sdv = vec;                          // PD ladder: current diagonal of A; bound: eta - mu (dense siginv only)
+    double *srd = vec;                          // inverse: 1 / diag(L)
     const double *S = P.siginv;
     double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
     constexpr int NT = NB * (NB + 1) / 2;
@@ -101,8 +107,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         for (int r = 0; r < 2; ++r) {
             const int k = lane + WAVE * r;
             thsv[r] = esv[r] / ssum;
-            sex[k] = exv[r];
-            sth[k] = (k < K) ? thsv[r] : 0.0;
+            if (k < NV) {
+                sex[k] = exv[r];
+                sth[k] = (k < K) ? thsv[r] : 0.0;
+            }
         }
         for (int q = lane; q < BT * TLD; q += WAVE) T[q] = 0.0;
         __syncthreads();
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                     double tv[8], ev[8], sv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int k = kb + kk + u < BT ? kb + kk + u : BT - 1;
+                        const int k = kb + kk + u < NV ? kb + kk + u : NV - 1;   // masked below when beyond the quarter
                         tv[u] = T[(size_t)k * TLD + fr]; ev[u] = sex[k]; sv[u] = sth[k];
                     }
 #pragma unroll
@@ -257,13 +265,9 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         // ---- H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv, formed on the accumulator
         // tiles and written to the HBM scratch (upper triangle: all that make_pd, the Cholesky and the dumps read);
         // the diagonal also goes to sdv
-        __syncthreads();
-        srd[lane] = rowc[0]; srd[lane + WAVE] = rowc[1];
+        // (the diagonal's -rowsum(c') + N theta + siginv_ii is applied by the lane that owns the row, below: it holds rowsum(c'))
         __syncthreads();
         {
-            double sdg[NB];   // siginv's diagonal at column 16 b + fr, all blocks' loads in flight at once
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { const int j = b * 16 + fr < n ? b * 16 + fr : n - 1; sdg[b] = S[(size_t)j * n + j]; }
             int t = 0;
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi)
@@ -276,13 +280,10 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : n - 1;
                         const double thi = sth[ic];
                         double h = hacc[t][r] - Ndoc * (thi * thj);
-                        if (bi == bj) h = (i == j) ? h - srd[ic] + Ndoc * thi : h;
-                        const double sij = (bi == bj && i == j) ? sdg[bj] : (P.siginv_diag ? 0.0 : S[(size_t)ic * n + jc]);
-                        const double v = h + sij;
-                        if (j < n && (bi != bj || (i <= j))) {
-                            Ag[(size_t)i * n + j] = v;
-                            if (bi == bj && i == j) sdv[i] = v;
-                        }
+                        const bool dg = bi == bj && i == j;
+                        const double sij = (dg || P.siginv_diag) ? 0.0 : S[(size_t)ic * n + jc];
+                        const double v = dg ? h : h + sij;     // the diagonal stays raw here
+                        if (j < n && (bi != bj || (i <= j))) Ag[(size_t)i * n + j] = v;
                     }
                 }
         }
@@ -292,11 +293,18 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         relane();
         // ---- PD ladder around one Cholesky (the upper triangle keeps A, L goes to the strict lower triangle)
         double diagA[2], Ldiag[2] = {1.0, 1.0};
+        // the diagonal, by the lane that owns the row: (h_ii - rowsum(c')_i) + N theta_i, + siginv_ii (stm.py:1003-1013), in that order
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int i = lane + WAVE * r;
-            diagA[r] = (i < n) ? sdv[i] : 1.0;
+            diagA[r] = 1.0;
+            if (i < n) {
+                const double h = Ag[(size_t)i * n + i];
+                diagA[r] = ((h - rowc[r]) + Ndoc * thsv[r]) + S[(size_t)i * n + i];
+                Ag[(size_t)i * n + i] = diagA[r];
+            }
         }
+        __syncthreads();   // every reader of theta (sth) is done: the vector now carries the diagonal
         auto make_pd = [&]() __attribute__((always_inline)) {  // stm.py:964-984
             // A comes from the HBM scratch: both rows of the lane and eight columns per round in flight, sums in column order
             const int i0 = k0 < n ? k0 : n - 1, i1 = k1 < n ? k1 : n - 1;
@@ -343,7 +351,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             // finished panels on the matrix cores, A read from the upper triangle (transposed) and the current diagonal
             // from sdv; (b) the panel itself with a lane's two rows in registers
             __syncthreads();
-            sdv[lane] = diagA[0]; sdv[lane + WAVE] = diagA[1];
+            sdv[lane] = diagA[0];
+            if (lane + WAVE < NV) sdv[lane + WAVE] = diagA[1];
             __syncthreads();
             // every pivot that passes lies in (32 eps, 1] x its diagonal entry (up to rounding): the range test of
             // sqrt_and_rsqrt can be made on the diagonal, once
@@ -392,8 +401,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                         const int i0 = bi * 16 + fq + 4 * r, i1 = i0 + 16;
                         // no masks: rows / columns beyond n are padding nobody reads, and what would land above the
                         // diagonal (where A lives) goes to the padding column instead
-                        M[(i0 >= bc && i0 < n) ? RS(i0) + bc : MDUMP + lane] = old0[r] - a0[r];
-                        if (two) M[i1 < n ? RS(i1) + bc : MDUMP + lane] = old1[r] - a1[r];
+                        M[(i0 >= bc && i0 < n) ? RS(i0) + bc : MDUMP] = old0[r] - a0[r];
+                        if (two) M[i1 < n ? RS(i1) + bc : MDUMP] = old1[r] - a1[r];
                     }
                 }
                 __syncthreads();
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
                     const int i = lane + WAVE * r;
 #pragma unroll
                     for (int c = 0; c < 16; ++c)   // rows on or above the diagonal write to the padding column instead
-                        M[(i < n && i > J0 + c) ? RS(i) + J0 + c : MDUMP + lane] = w[r][c];
+                        M[(i < n && i > J0 + c) ? RS(i) + J0 + c : MDUMP] = w[r][c];
                 }
                 __syncthreads();
             }
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             Rdiag[r] = 1.0 / Ldiag[r];
-            srd[lane + WAVE * r] = (lane + WAVE * r < n) ? Rdiag[r] : 0.0;
+            if (lane + WAVE * r < NV) srd[lane + WAVE * r] = (lane + WAVE * r < n) ? Rdiag[r] : 0.0;
         }
         __syncthreads();
         long long ti[3] = {0, 0, 0};
