@@ -79,6 +79,16 @@ __global__ void transpose_kernel(const double *in, double *out, int R, int C) {
         if (orow + dy < C && oc < R) out[base + (size_t)(orow + dy) * R + oc] = tile[threadIdx.x][threadIdx.y + dy];
 }
 
+// colsum[a][w] = sum_k betaT[a][w][k], added in topic order (what np.sum(beta_doc_kv, axis=0) of stm.py:954 gives for the word's column)
+__global__ void beta_colsum_kernel(const double *betaT, int64_t AV, int K, double *colsum) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= AV) return;
+    const double *row = betaT + r * K;
+    double t = 0.0;
+    for (int k = 0; k < K; ++k) t += row[k];
+    colsum[r] = t;
+}
+
 // small device -> pinned-host copy done by the GPU itself (no DMA engine round trip)
 __global__ void copy_out_kernel(const double *src, double *dst, size_t cnt) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,7 +113,7 @@ struct stm_handle {
     double *d_counts = nullptr;
     // model
     int K = 0, n = 0;
-    double *d_betaT = nullptr, *d_tmpKV = nullptr;
+    double *d_betaT = nullptr, *d_tmpKV = nullptr, *d_colsum = nullptr;
     double *d_beta_ssT = nullptr, *d_sigma_ss = nullptr, *d_scal = nullptr;  // views into d_pack
     double *d_eta = nullptr, *d_mu = nullptr, *d_theta = nullptr, *d_bound = nullptr;
     double *d_siginv = nullptr, *d_sigma_part = nullptr;
@@ -302,7 +312,7 @@ void stm_destroy(stm_handle *h) {
     stm_mstep_comm_destroy(h->comm);
     stm_spectral_destroy(h->spectral);
     dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
-    dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_eta); dfree(h->d_mu);
+    dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_colsum); dfree(h->d_eta); dfree(h->d_mu);
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
     dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
@@ -397,6 +407,7 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     h->p = 0;
     dfree(h->d_X);
     if (int rc = dalloc(&h->d_tmpKV, KV)) return rc;
+    if (int rc = dalloc(&h->d_colsum, (size_t)h->A * h->V)) return rc;
     if (int rc = dalloc(&h->d_eta, N * n)) return rc;
     if (int rc = dalloc(&h->d_mu, N * n)) return rc;
     if (int rc = dalloc(&h->d_theta, N * K)) return rc;
@@ -442,6 +453,14 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     return STM_OK;
 }
 
+// after every change of betaT: the per-word column sums the solver divides the counts by
+static int refresh_colsum(stm_handle *h) {
+    const int64_t AV = (int64_t)h->A * h->V;
+    hipLaunchKernelGGL(beta_colsum_kernel, dim3((unsigned)((AV + 255) / 256)), dim3(256), 0, h->stream, (const double *)h->d_betaT, AV, h->K, h->d_colsum);
+    HIP_TRY(hipGetLastError());
+    return STM_OK;
+}
+
 static int transpose3(stm_handle *h, const double *in, double *out, int R, int C) {
     dim3 blk(32, 8), grd((C + 31) / 32, (R + 31) / 32, h->A);
     hipLaunchKernelGGL(transpose_kernel, grd, blk, 0, h->stream, in, out, R, C);
@@ -459,6 +478,7 @@ int stm_put_beta(stm_handle *h, const double *beta) {
     const size_t KV = (size_t)h->A * h->K * h->V;
     HIP_TRY(hipMemcpyAsync(h->d_tmpKV, beta, sizeof(double) * KV, hipMemcpyHostToDevice, h->stream));
     if (int rc = transpose3(h, h->d_tmpKV, h->d_betaT, h->K, h->V)) return rc;
+    if (int rc = refresh_colsum(h)) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->beta_set = true;
     return STM_OK;
@@ -581,7 +601,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     stm::SolverParams sp{};
     sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = h->KP;
     sp.indptr = h->d_indptr; sp.indices = h->d_indices; sp.counts = h->d_counts; sp.aspect = h->d_aspect;
-    sp.betaT = h->d_betaT; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag; sp.sig_bound = sig_bound;
+    sp.betaT = h->d_betaT; sp.colsum = h->d_colsum; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag; sp.sig_bound = sig_bound;
     sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
     sp.order = h->d_order; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
     sp.err_flag = h->d_err;

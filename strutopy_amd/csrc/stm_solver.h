@@ -42,6 +42,8 @@ struct SolverParams {
     const double *counts;
     const int32_t *aspect;  // nullable
     const double *betaT;    // [A][V][K]
+    const double *colsum;   // [A][V] sum_k beta[k][w] in topic order (np.sum(beta_doc_kv, axis=0), stm.py:954): a property of the word,
+                            // computed once per EM iteration (stm_api.hip: beta_colsum_kernel) instead of once per document
     const double *mu;       // [N][n]
     double *eta;            // [N][n] in/out
     const double *siginv;   // [n][n]
@@ -284,7 +286,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         const int idx_reg = act ? P.indices[p0 + wreg] : 0;
         const int idx_slab = (COOP && lane < NdL) ? P.indices[p0 + VREG + lane] : 0;
         const double cnt_slab = (COOP && lane < NdL) ? P.counts[p0 + VREG + lane] : 0.0;
-        if (act) c0 = P.counts[p0 + wreg];
+        double cs0 = 1.0;
+        const double *csv = P.colsum + (size_t)asp * (size_t)P.V;
+        if (act) { c0 = P.counts[p0 + wreg]; cs0 = csv[idx_reg]; }
+        const double cs_slab = (COOP && lane < NdL) ? csv[idx_slab] : 1.0;
         if (KREG > 0) {
             // unconditional loads of KREG doubles from the row start (the buffer is padded; rows are 16-byte aligned for even K),
             // zeros beyond K by selection: no branch per topic
@@ -315,14 +320,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             __builtin_amdgcn_sched_barrier(0);
         }
         if (KREG > 0) {
-            double colsum = 0.0;
 #pragma unroll
-            for (int k = 0; k < KR; ++k) {
-                bad |= !(breg[k] >= 0.0);
-                colsum += breg[k];
-            }
+            for (int k = 0; k < KR; ++k) bad |= !(breg[k] >= 0.0);
             if (act) {
-                w0 = c0 / colsum;
+                w0 = c0 / cs0;
                 csum += c0;
             }
         }
@@ -416,18 +417,9 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             STM_WAVE_SYNC();
             for (int vv = lane; vv < NdL; vv += WAVE) {
                 const double c = vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
+                const double colsum = vv < WAVE ? cs_slab : csv[P.indices[p0 + VREG + vv]];
                 double *dst = slab + (size_t)vv * KP;
-                double colsum = 0.0;
-                int k = 0;
-                for (; k + 7 < K; k += 8) {   // eight LDS reads in flight, the additions stay in order
-                    double t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = dst[k + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) colsum += t[u];
-                }
-                for (; k < K; ++k) colsum += dst[k];
-                for (k = K; k < KP; ++k) dst[k] = 0.0;
+                for (int k = K; k < KP; ++k) dst[k] = 0.0;
                 crow[vv] = c;
                 wrow[vv] = c / colsum;
             }
@@ -475,21 +467,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 tile_store();
                 STM_WAVE_SYNC();
                 if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
-                // (a) column sums (np.sum(beta_d, axis=0)) and the beta >= 0 assertion (stm.py:534)
-                {
-                    const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);
-                    double c0s = 0.0, c1s = 0.0;
-                    const int k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
-                    for (int kk = dq * kq2; kk < k1; ++kk) {
-                        const double2 b = tr[kk];
-                        bad |= !(b.x >= 0.0) | !(b.y >= 0.0);
-                        c0s += b.x; c1s += b.y;
-                    }
-                    double cs = c0s + c1s;
-                    cs += __shfl_xor(cs, 16);
-                    cs += __shfl_xor(cs, 32);
-                    if (dq == 0 && dw < nw) wrow[t0 + dw] = crow[t0 + dw] / cs;
-                }
+                // (a) c / colsum(beta_d): the column sum is a property of the word (P.colsum)
+                if (lane < nw) wrow[t0 + lane] = crow[t0 + lane] / csv[sidx[t0 + lane]];
                 STM_WAVE_SYNC();
                 // (b) g0 += beta_d[:, tile] @ (c / colsum), lane = topic
 #pragma unroll 4
@@ -497,7 +476,11 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     const double wq = wrow[t0 + w];
 #pragma unroll
                     for (int r = 0; r < VPL; ++r)
-                        if (lane + WAVE * r < KP) g0a[r] = fma(slab[(size_t)w * KP + lane + WAVE * r], wq, g0a[r]);
+                        if (lane + WAVE * r < KP) {
+                            const double bv = slab[(size_t)w * KP + lane + WAVE * r];
+                            bad |= !(bv >= 0.0);     // assert beta >= 0 (stm.py:534): every entry of the tile passes here
+                            g0a[r] = fma(bv, wq, g0a[r]);
+                        }
                 }
                 STM_WAVE_SYNC();
             }

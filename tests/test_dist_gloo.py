@@ -92,7 +92,8 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind):
     ref.expectation_maximization(saving=False)
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == full.N
     for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma in res:
-        assert np.allclose(bounds, ref.last_bounds, rtol=1e-11)            # the ELBO is the all-reduced sum
+        # the ELBO is the all-reduced sum; the second iteration sees the first one's 1e-16 summation-order differences amplified
+        assert np.isclose(bounds[0], ref.last_bounds[0], rtol=1e-12) and np.allclose(bounds, ref.last_bounds, rtol=1e-9)
         assert np.allclose(sigma, ref.sigma, rtol=1e-8, atol=1e-12)
         assert np.allclose(beta, ref.beta, rtol=1e-8, atol=1e-14)
         assert np.allclose(mu, ref.mu[lo:hi], atol=1e-9) and np.allclose(eta, ref.eta[lo:hi], atol=1e-8)
