@@ -13,7 +13,9 @@
 
 #include "../../include/stm_estep.h"
 #include "stm_mstep.h"
+#include "stm_betass.h"
 #include "stm_post.h"
+#include "stm_post_v1.h"
 #include "stm_post_big.h"
 #include "stm_solver.h"
 
@@ -111,6 +113,12 @@ struct stm_handle {
     int64_t *d_indptr = nullptr;
     int32_t *d_indices = nullptr, *d_aspect = nullptr, *d_order = nullptr;
     double *d_counts = nullptr;
+    // the corpus in word-major order (stm_betass.h): entries sorted by (level, word), ascending document within a row
+    int32_t *d_wm_doc = nullptr, *d_wm_pos = nullptr, *d_seg_row = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
+    uint8_t *d_seg_multi = nullptr;
+    int64_t nseg = 0;
+    double *d_rw = nullptr;     // [nnz] r_dw written by the post kernel
+    size_t sigma_part_len = 0;
     // model
     int K = 0, n = 0;
     double *d_betaT = nullptr, *d_tmpKV = nullptr, *d_colsum = nullptr;
@@ -171,6 +179,10 @@ static int use_device(stm_handle *h) {
 
 
 using SolverFn = void (*)(stm::SolverParams);
+
+#ifndef POST_WPE
+#define POST_WPE 3   // waves per SIMD the K <= 64 post kernel is register-budgeted for (twelve single-wave workgroups per CU)
+#endif
 
 // solver instantiations: KREG topics of the register-resident words (0: none), LDS or global slab,
 // one or two wavefronts per document
@@ -312,6 +324,7 @@ void stm_destroy(stm_handle *h) {
     stm_mstep_comm_destroy(h->comm);
     stm_spectral_destroy(h->spectral);
     dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
+    dfree(h->d_wm_doc); dfree(h->d_wm_pos); dfree(h->d_seg_row); dfree(h->d_seg_lo); dfree(h->d_seg_hi); dfree(h->d_seg_multi); dfree(h->d_rw);
     dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_colsum); dfree(h->d_eta); dfree(h->d_mu);
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
@@ -382,6 +395,52 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     if (N) HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
     h->h_len_sorted.resize((size_t)N);
     for (int64_t i = 0; i < N; ++i) h->h_len_sorted[(size_t)i] = (int32_t)(indptr[order[i] + 1] - indptr[order[i]]);
+    // word-major order (stm_betass.h): a counting sort of the CSR positions by (level, word); documents ascend within a row
+    if (nnz >= (int64_t)1 << 31) return fail(STM_ERR_INVALID, "stm_set_corpus: nnz must be < 2^31 per GPU shard");
+    {
+        const size_t R = (size_t)A * (size_t)V;
+        std::vector<int32_t> cnt(R + 1, 0);
+        for (int64_t d = 0; d < N; ++d) {
+            const size_t base = (aspect && A > 1 ? (size_t)aspect[d] : 0) * (size_t)V;
+            for (int64_t q = indptr[d]; q < indptr[d + 1]; ++q) ++cnt[base + (size_t)indices[q] + 1];
+        }
+        for (size_t r = 0; r < R; ++r) cnt[r + 1] += cnt[r];
+        std::vector<int32_t> wm_doc((size_t)nnz), wm_pos((size_t)nnz), fill(cnt.begin(), cnt.end() - 1);
+        for (int64_t d = 0; d < N; ++d) {
+            const size_t base = (aspect && A > 1 ? (size_t)aspect[d] : 0) * (size_t)V;
+            for (int64_t q = indptr[d]; q < indptr[d + 1]; ++q) {
+                const int32_t slot = fill[base + (size_t)indices[q]]++;
+                wm_doc[(size_t)slot] = (int32_t)d;
+                wm_pos[(size_t)slot] = (int32_t)q;
+            }
+        }
+        std::vector<int32_t> seg_row, seg_lo, seg_hi;
+        std::vector<uint8_t> seg_multi;
+        for (size_t r = 0; r < R; ++r) {
+            const int32_t lo = cnt[r], hi = cnt[r + 1];
+            for (int32_t b = lo; b < hi; b += stm::BETASS_SEG) {
+                seg_row.push_back((int32_t)r); seg_lo.push_back(b); seg_hi.push_back(std::min(hi, b + stm::BETASS_SEG));
+                seg_multi.push_back(hi - lo > stm::BETASS_SEG ? 1 : 0);
+            }
+        }
+        h->nseg = (int64_t)seg_row.size();
+        if (int rc = dalloc(&h->d_wm_doc, (size_t)nnz)) return rc;
+        if (int rc = dalloc(&h->d_wm_pos, (size_t)nnz)) return rc;
+        if (int rc = dalloc(&h->d_rw, (size_t)nnz)) return rc;
+        if (int rc = dalloc(&h->d_seg_row, seg_row.size())) return rc;
+        if (int rc = dalloc(&h->d_seg_lo, seg_row.size())) return rc;
+        if (int rc = dalloc(&h->d_seg_hi, seg_row.size())) return rc;
+        if (int rc = dalloc(&h->d_seg_multi, seg_row.size())) return rc;
+        if (nnz) {
+            HIP_TRY(hipMemcpyAsync(h->d_wm_doc, wm_doc.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_wm_pos, wm_pos.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_seg_row, seg_row.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_seg_lo, seg_lo.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_seg_hi, seg_hi.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_seg_multi, seg_multi.data(), seg_row.size(), hipMemcpyHostToDevice, h->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));   // the host vectors go out of scope
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->K = 0;
     return STM_OK;
@@ -394,7 +453,9 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = use_device(h)) return rc;
     h->K = K; h->n = K - 1;
     const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
-    if (int rc = dalloc(&h->d_betaT, KV + 64)) return rc;   // + 64: the solver reads KREG <= 64 doubles from a row start, masked beyond K
+    if ((size_t)K * h->V * sizeof(double) >= ((size_t)1 << 32)) return fail(STM_ERR_INVALID, "stm_set_topics: one level of beta must stay below 4 GiB (32-bit row offsets)");
+    if (int rc = dalloc(&h->d_betaT, KV + 64)) return rc;   // + 64: the kernels read whole 16-byte pieces / KREG <= 64 doubles from a row start, masked beyond K
+    HIP_TRY(hipMemsetAsync(h->d_betaT + KV, 0, sizeof(double) * 64, h->stream));   // ... and what they mask must be finite
     // one packed buffer [ scalars(8) | sigma_ss | moments | beta_ss ] so a single all-reduce covers it
     h->extra_cap = round64(moments_len(8, h->n));
     h->pack_len = 8 + n * n + h->extra_cap + KV;
@@ -433,7 +494,8 @@ int stm_set_topics(stm_handle *h, int32_t K) {
             if (h->nw == 1 || gr.global) need = std::max<int64_t>(need, std::min<int64_t>(gr.count, h->chunk));
         if (int rc = dalloc(&h->d_slab_H, (size_t)std::max<int64_t>(need, 1) * n * n)) return rc;
     }
-    if (int rc = dalloc(&h->d_sigma_part, (size_t)h->nrep * n * n)) return rc;
+    h->sigma_part_len = 0;
+    if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)h->nrep * n * n)) return rc;
     HIP_TRY(hipMemsetAsync(h->d_eta, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_mu, 0, sizeof(double) * std::max<size_t>(N * n, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_theta, 0, sizeof(double) * std::max<size_t>(N * K, 1), h->stream));
@@ -588,7 +650,6 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     } else {
         HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     }
-    HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)h->nrep * n * n, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
     // last document's phi is what the reference leaves in self.phi (stm.py:1116)
@@ -621,6 +682,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     pp.prof = h->d_prof;
 
     const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
+    int nrep = h->nrep;
+    size_t slab = (size_t)h->n * h->n;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
@@ -643,44 +706,79 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         // persistent single-wave workgroups: as many as the LDS / register budget keeps resident
         using PostFn = void (*)(stm::PostParams);
         // the matrix is n x n (n = K - 1): 16 x 16 MFMA blocks, and when n is one past a multiple of 16
-        // (K = 50: 49 = 3 * 16 + 1) the last row / column rides on the VALU instead of a padded block
+        // (K = 50: 49 = 3 * 16 + 1) the last row / column of b b^T rides on the VALU instead of a padded block
         const bool rem = n > 16 && n % 16 == 1 && env_int("STM_POST_REM", 1);
         const int nb = rem ? n / 16 : (n + 15) / 16;
-        const bool dumps = pp.nu_out != nullptr;
+        const bool dbg = pp.nu_out != nullptr || pp.prof != nullptr || pp.debug_flags != 0;
+        const bool v1 = env_int("STM_POST_IMPL", 0) == 1;   // the round-2 kernel, for A/B runs
         PostFn pf;
-        if (rem)
-            pf = dumps ? (nb == 1 ? stm::post_kernel<1, 1, true> : nb == 2 ? stm::post_kernel<2, 1, true> : stm::post_kernel<3, 1, true>)
-                       : (nb == 1 ? stm::post_kernel<1, 1, false> : nb == 2 ? stm::post_kernel<2, 1, false> : stm::post_kernel<3, 1, false>);
-        else
-            pf = dumps ? (nb <= 1 ? stm::post_kernel<1, 0, true> : nb == 2 ? stm::post_kernel<2, 0, true>
-                          : nb == 3 ? stm::post_kernel<3, 0, true> : stm::post_kernel<4, 0, true>)
-                       : (nb <= 1 ? stm::post_kernel<1, 0, false> : nb == 2 ? stm::post_kernel<2, 0, false>
-                          : nb == 3 ? stm::post_kernel<3, 0, false> : stm::post_kernel<4, 0, false>);
-        const bool big = K > stm::PT;   // two topics per lane, VALU only (stm_post_big.h)
-        pp.MLD = big ? stm::post_big_mld(n) : stm::post_mld(n);
+        if (v1) {
+            const bool dumps = pp.nu_out != nullptr;
+            if (rem)
+                pf = dumps ? (nb == 1 ? stm::post_kernel_v1<1, 1, true> : nb == 2 ? stm::post_kernel_v1<2, 1, true> : stm::post_kernel_v1<3, 1, true>)
+                           : (nb == 1 ? stm::post_kernel_v1<1, 1, false> : nb == 2 ? stm::post_kernel_v1<2, 1, false> : stm::post_kernel_v1<3, 1, false>);
+            else
+                pf = dumps ? (nb <= 1 ? stm::post_kernel_v1<1, 0, true> : nb == 2 ? stm::post_kernel_v1<2, 0, true>
+                              : nb == 3 ? stm::post_kernel_v1<3, 0, true> : stm::post_kernel_v1<4, 0, true>)
+                           : (nb <= 1 ? stm::post_kernel_v1<1, 0, false> : nb == 2 ? stm::post_kernel_v1<2, 0, false>
+                              : nb == 3 ? stm::post_kernel_v1<3, 0, false> : stm::post_kernel_v1<4, 0, false>);
+        } else if (rem) {
+            pf = dbg ? (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, true> : stm::post_kernel<3, 1, POST_WPE, true>)
+                     : (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, false> : stm::post_kernel<3, 1, POST_WPE, false>);
+        } else {
+            pf = dbg ? (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, true>
+                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, true> : stm::post_kernel<4, 0, 2, true>)
+                     : (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, false>
+                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
+        }
+        const bool big = K > stm::PT;   // two topics per lane (stm_post_big.h)
+        pp.MLD = big ? stm::post_big_mld(n) : stm::post_v1_mld(n);
         const int nbb = (n + 15) / 16;
         const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
                            : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
         const PostFn pfn = big ? pfb : pf;
-        const size_t lds = (big ? stm::post_big_lds_doubles(n) : stm::post_lds_doubles(n, pp.MLD, K)) * sizeof(double);
+        const size_t lds = (big ? stm::post_big_lds_doubles(n) : v1 ? stm::post_v1_lds_doubles(n, pp.MLD, K) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
         pp.lds_doubles = (int)(lds / sizeof(double));
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, 64, lds));
-        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 8)));
+        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 16)));
         const int64_t grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
         if (big) {   // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
             if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * n * n)) return rc;
             pp.a_scratch = h->d_ascratch;
         }
         pp.first = 0; pp.count = h->N;
+        // nu is summed per workgroup in a slab of its own (post_kernel: plain read-modify-write, nrep = grid) or
+        // atomically into nrep replicas (post_kernel_v1, post_big_kernel); reduce_sigma_kernel adds them in a fixed order
+        nrep = (big || v1) ? h->nrep : (int)grid;
+        const int nbc = (n + 15) / 16;
+        slab = (big || v1) ? (size_t)n * n : (size_t)(nbc * (nbc + 1) / 2) * 256;   // post_kernel: accumulator-tile layout
+        if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
+        HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
+        pp.sigma_part = h->d_sigma_part; pp.nrep = nrep;
+        pp.rw = h->d_rw;
         hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
+        if (!big && !v1 && h->nseg > 0) {   // beta_ss from the r_dw the post kernel left behind (stm_betass.h)
+            stm::BetaSsParams bp{};
+            bp.K = K; bp.nseg = h->nseg; bp.seg_row = h->d_seg_row; bp.seg_lo = h->d_seg_lo; bp.seg_hi = h->d_seg_hi; bp.seg_multi = h->d_seg_multi;
+            bp.wm_doc = h->d_wm_doc; bp.wm_pos = h->d_wm_pos; bp.rw = h->d_rw; bp.theta = h->d_theta; bp.betaT = h->d_betaT; bp.beta_ssT = h->d_beta_ssT;
+            hipLaunchKernelGGL(stm::beta_ss_kernel, dim3((unsigned)((h->nseg + 3) / 4)), dim3(256), 0, h->stream, bp);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((n * n + 63) / 64), dim3(256), 0, h->stream,
-                       h->d_sigma_part, h->nrep, n * n, h->d_sigma_ss);
-    if (K > stm::PT) hipLaunchKernelGGL(stm::mirror_blocks_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, h->d_sigma_ss, n);
+    if (slab == (size_t)n * n) {
+        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((n * n + 63) / 64), dim3(256), 0, h->stream,
+                           h->d_sigma_part, nrep, n * n, h->d_sigma_ss);
+        hipLaunchKernelGGL(stm::mirror_blocks_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, h->d_sigma_ss, n);
+    } else {   // post_kernel's slabs: summed in their tile layout, then laid out as the matrix
+        double *tiles = h->d_sigma_part + (size_t)nrep * slab;
+        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, h->stream,
+                           h->d_sigma_part, nrep, (int)slab, tiles);
+        hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss);
+    }
     hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));

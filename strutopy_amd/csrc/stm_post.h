@@ -1,142 +1,127 @@
-// stm_post.h -- per-document theta / Hessian / Cholesky / nu / bound / phi after the solve.
+// stm_post.h -- per-document theta / Hessian / Cholesky / nu / bound / phi after the solve, K <= 64.
 //
 // Replaces, per document, reference src/modules/stm.py:547-588:
 //   theta (547-549), hessian (986-1026, incl. make_pd 964-984 and the +1e-5 branch),
 //   decompose_hessian (1031-1050), lower_bound (1068-1101), optimize_nu (1052-1066),
 //   update_z (1103-1118) and the sigma_ss / beta_ss accumulation (582-588).
 //
-// One wavefront per workgroup, PERSISTENT over a strided set of documents.  Per document the
-// words are processed in tiles of 16:
-//   1. gather   lane = topic: the tile's 16 beta rows are read from betaT[A][V][K] as 16
-//               coalesced 8K-byte runs and transposed into the LDS tile T[topic][word]
-//   2. reduce   lane = (word, quarter of the topics): colsum S_w and theta.(beta*exp(eta)) per
-//               word, two cross-lane steps; log / sqrt / reciprocal once per word
-//   3. scatter  lane = topic: phi = a*c/S is atomically added to beta_ssT[word][:] -- again one
-//               coalesced 8K-byte run per word (fp64 hardware atomics) -- and T is overwritten
-//               with b = a*sqrt(c)/S
-//   4. b b^T    fp64 MFMA (v_mfma_f64_16x16x4_f64): the K x K contraction, upper block triangle
-//               only, accumulated in registers over all tiles of the document
-// The (K-1)^2 matrix then lives in one LDS array M (aliasing T): Cholesky overwrites the strict
-// lower triangle with L, the untouched upper triangle still holds A for the make_pd fallbacks,
-// and X = L^-1 then takes L's place (16 x 16 diagonal blocks by substitution, the blocks below them
-// on the matrix cores).  nu = X^T X = H^-1 is again a Gram product
-// and is accumulated ON THE MATRIX CORES ACROSS ALL DOCUMENTS of the workgroup
-// (sigma_ss = sum_d R_d R_d^T); one atomic flush per workgroup at the end of the launch.
+// One wavefront per workgroup, PERSISTENT over a strided set of documents, and built to be RESIDENT TWELVE TO A CU
+// (three waves per SIMD: <= 168 registers, 10.7 KB of LDS at K = 50) -- every phase of a document is a chain of
+// dependent instructions, and what hides one wave's latencies is the other waves of its SIMD.
+//
+// Words are processed in tiles of 16, word-major in LDS (T[word][topic], exactly the layout of betaT's rows):
+//   0. fetch    the tile's 16 beta rows go from betaT[A][V][K] STRAIGHT INTO LDS (global_load_lds_dwordx4: lane l of
+//               instruction q moves 16-byte chunk 64 q + l of the tile) -- no staging registers, no transposition, and the
+//               fetch of tile t+1 is issued as soon as the matrix cores have read tile t
+//   1. sums     lane = (word, quarter of the topics): colsum S_w and theta.(beta*exp(eta)) per word; the four quarters sit
+//               in one DPP quad; log / sqrt / division once per word
+//   2. scatter  lane = topic: phi = a*c/S is atomically added to beta_ssT[word][:] -- one coalesced 8K-byte run per word
+//               (fp64 hardware atomics) -- and T is overwritten with b = a*sqrt(c)/S
+//   3. b b^T    fp64 MFMA (v_mfma_f64_16x16x4_f64): the K x K contraction, upper block triangle only, accumulated in
+//               registers over all tiles of the document
+// The (K-1)^2 matrix then lives in LDS as its LOWER TRIANGLE ONLY, row-packed (rows padded to an even length: 16-byte
+// rows), aliasing the tile: the blocked Cholesky (block-column updates on the matrix cores, 16-column panels factorised
+// right-looking in registers with v_readlane broadcasts) overwrites it with L, the blocked in-place inverse with X = L^-1,
+// and nu = X^T X = H^-1 is a Gram product again (matrix cores, only the tiles and the k-range the triangular shape leaves),
+// added per document into 256 replicated accumulators.  A failed rung of the reference's PD ladder finds A again by
+// re-running the assembly from the b b^T accumulators, which stay in registers until the ladder is through.
 #pragma once
-#include <type_traits>
-#include "stm_wave.h"
+#include "stm_post_common.h"
 
 namespace stm {
 
-struct PostParams {
-    int64_t N;
-    int K, n, V;
-    const int64_t *indptr;
-    const int32_t *indices;
-    const double *counts;
-    const int32_t *aspect;
-    const double *betaT;   // [A][V][K]
-    const double *mu;      // [N][n]
-    const double *eta;     // [N][n]
-    const double *siginv;  // [n][n]
-    int siginv_diag;
-    double sigmaentropy;
-    double *theta;         // [N][K]
-    double *bound;         // [N]
-    double *beta_ssT;      // [A][V][K], pre-zeroed, atomically accumulated
-    double *sigma_part;    // [nrep][n][n] replicated accumulators of nu (pre-zeroed, atomics)
-    int nrep;
-    int64_t first;         // this launch covers order[first .. first + count)
-    int64_t count;
-    const int32_t *order;
-    int32_t *pd_path;
-    int32_t *err_flag;
-    double *hess_out, *chol_out, *nu_out;  // optional [N][n][n] dumps (nullable)
-    int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky;
-                           // 16 (tests): NaN into the whole LDS allocation before every document
-    int lds_doubles;       // size of the dynamic LDS allocation
-    double *a_scratch;     // post_big_kernel: [grid][n][n] A = H + fixes, upper triangle (per-workgroup scratch)
-    int64_t phi_doc;       // document whose phi is dumped (-1: none)
-    double *phi_out;       // [K][Nd(phi_doc)]
-    int MLD;               // leading dimension of the LDS matrix (odd, >= n)
-    long long *prof;       // optional [N][40] (shared with the solver's): [32..39] post-kernel phase cycles
+// start of row i of the row-packed lower triangle (row i: i + 1 cells, padded to an even count)
+__host__ __device__ inline int tri_row(int i) { return 2 * ((i + 1) >> 1) * ((i >> 1) + 1); }
+
+// LDS map (doubles).  Region 0 is the word tile + its per-word / per-topic vectors during the word loop and the packed
+// matrix afterwards; one 64-entry per-topic vector (theta -> eta - mu -> 1 / diag L) lives behind it.  The tile's row
+// pitch is a property of the instantiation: NB blocks serve K <= 16 NB + 2 topics, i.e. rows of at most 8 NB + 1 16-byte
+// chunks -- every tile offset is an immediate (K = 50: NB = 3, 25 chunks, exactly betaT's row).
+struct PostLds {
+    int pitch;   // tile row pitch in doubles: 16 NB + 2
+    int qp;      // 16-byte chunks per quarter of a row in the per-word sums: ceil((8 NB + 1) / 4)
+    int tile;    // doubles per tile buffer (two of them: the fetch of tile t+1 is issued before tile t is touched)
+    int zp;      // zeros behind the second tile (the last quarter reads a few chunks past the last row)
+    int wpar;    // per word { sqrt(c) / S, sqrt(c) }
+    int sex;     // exp(eta~) per topic, zeros from K on (8 qp entries)
+    int eth;     // exp(eta~) * stable_softmax(eta~) per topic, zeros from K on
+    int mdump;   // two cells behind the matrix (+ 16 of slack) that masked stores go to
+    int vec;     // the per-topic vector of the factor phases, behind the matrix
+    int total;
 };
-
-// A Cholesky pivot that is only the rounding left over from cancelling the diagonal entry counts as failed (as in the
-// oracle): make_pd can leave an exactly singular matrix (n = 2: always when both diagonals are raised), and the sign of such a
-// pivot -- like the sign of the smallest eigenvalue the reference tests, stm.py:1017 -- hangs on the last bit of the input.
-constexpr double PIVOT_TOL = 32.0 * 2.220446049250313e-16;
-constexpr int PT = 64;    // topics padded to 64 (K <= 64 in this kernel)
-constexpr int TW = 16;    // words per tile
-constexpr int TLD = 18;   // leading dimension of T: MFMA fragment reads are conflict-free
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-// LDS hand-off between lanes of the (single) wave of a workgroup: the LDS executes a wave's operations in
-// order, so only the compiler must not reorder them -- unlike __syncthreads() this does not drain the
-// global loads that are deliberately kept in flight across the hand-off
-#define STM_POST_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-
-#ifndef STM_POST_WPE
-#define STM_POST_WPE 2   // waves per SIMD the post kernel is register-budgeted for
-#endif
-
-// Leading dimension of the LDS matrix: rows start 16-byte aligned and are read two doubles at a time
-// (ds_read_b128); MLD = 2 * odd makes the 16-lane groups of such a lane-strided read hit distinct bank quads
-// (tools/microbench/lds_read.hip: 1.5x the throughput of ds_read_b64 at an odd stride).
-inline int post_mld(int n) {
-    int m = n + (n & 1);
-    if ((m & 3) != 2) m += 2;
-    return m;
-}
-// entries of the two per-topic LDS vectors: the per-word sums read topics [0, 4 * ceil(K / 4))
-__host__ __device__ inline int post_vec_len(int K) { return 4 * ((K + 3) >> 2); }
-// doubles of dynamic LDS: region 0 = max(T + per-word pack, M), then two per-topic vectors whose contents
-// change with the phase (20.4 KB at K = 50: eight workgroups per CU)
-inline size_t post_lds_doubles(int n, int MLD, int K) {
-    const size_t t = (size_t)PT * TLD + 4 * TW, m = (size_t)n * MLD;
-    return (t > m ? t : m) + 2 * (size_t)post_vec_len(K);
+__host__ __device__ constexpr int post_pitch(int NB) { return 16 * NB + 2; }
+__host__ __device__ inline PostLds post_lds_map(int K, int NB) {
+    PostLds L;
+    const int n = K - 1;
+    L.pitch = post_pitch(NB);
+    L.qp = (8 * NB + 1 + 3) / 4;
+    L.tile = TW * L.pitch + 8;          // + 8: what the last quarter of the first buffer's last row reads past it must be finite too
+    L.zp = 2 * L.tile - 8;
+    L.wpar = 2 * L.tile;
+    L.sex = L.wpar + 2 * TW;
+    L.eth = L.sex + 8 * L.qp;
+    const int tile_part = L.eth + 8 * L.qp;
+    L.mdump = tri_row(n) + 16;
+    L.vec = L.mdump + 2;
+    const int mat_part = L.vec + 64;
+    L.total = ((tile_part > mat_part ? tile_part : mat_part) + 1) & ~1;
+    return L;
 }
 
-// NB 16 x 16 blocks cover the (K-1)^2 matrix on the matrix cores; REM == 1: n = 16 NB + 1 exactly (K = 50:
-// 49 = 3 * 16 + 1), and the one row / column beyond the blocks is carried on the VALU (one double per
-// lane) instead of padding to NB + 1 blocks -- 6 accumulator tiles instead of 10, twice (b b^T and nu).
-template <int NB, int REM, bool DUMP>
-__global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
+// explicit waits (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]) as builtins, so that the compiler's
+// own counter bookkeeping sees them
+__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0)
+__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // lgkmcnt(0)
+template <int N> __device__ __forceinline__ void wait_vmem_but() {   // vmcnt(N): all but the N youngest memory operations
+    static_assert(N >= 0 && N < 64, "vmcnt is a six-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+// ties a value to its place among the memory operations (a pure computation is otherwise free to be selected anywhere)
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v) :: "memory"); }
+
+// NB 16 x 16 blocks cover the b b^T accumulation on the matrix cores; REM == 1: n = 16 NB + 1 exactly (K = 50:
+// 49 = 3 * 16 + 1), and the one row / column beyond the blocks is carried on the VALU (one double per lane) instead of
+// padding to NB + 1 blocks -- 6 accumulator tiles instead of 10.  The factorisation, the inverse and nu work on
+// NBC = ceil(n / 16) blocks either way (a one-row block costs them four matrix-core passes).
+// WPE: waves per SIMD the registers are budgeted for.  DBG: per-document dumps, cycle counters, LDS poisoning.
+template <int NB, int REM, int WPE, bool DBG>
+__global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
     constexpr int NT = NB * (NB + 1) / 2;
-    constexpr int R0 = 16 * NB;   // index of the remainder row (REM == 1)
+    constexpr int R0 = 16 * NB;       // index of the remainder row (REM == 1)
+    constexpr int NBC = NB + REM;
+    constexpr int PITCH = post_pitch(NB), PC = PITCH / 2;   // tile row pitch in doubles / 16-byte chunks
+    constexpr int QP = (PC + 3) / 4;                         // chunks per quarter row in the per-word sums
+    constexpr int NQ = (TW * PC + 63) / 64;                  // LDS-DMA instructions per tile (the last one: 16 lanes)
     extern __shared__ __attribute__((aligned(16))) double post_lds[];
     int lane = threadIdx.x;
-    const int K = P.K, n = P.n, MLD = P.MLD;
-    double *T = post_lds;  // [PT][TLD]
-    double *M = post_lds;  // [n][MLD] (after the word loop)
-    double *wpar = post_lds + (size_t)PT * TLD;  // word-tile phase only, behind T: per word { sqrt(c), S, 1/S, sqrt(c)/S }
-    double *vec = post_lds + ((size_t)PT * TLD + 4 * TW > (size_t)n * MLD ? (size_t)PT * TLD + 4 * TW : (size_t)n * MLD);
-    double *sex = vec;            // word tiles: exp(eta~) (unshifted, stm.py:1000,1088,1114) ...
-    double *srd = vec;            // ... after the factorisation: 1 / diag(L)
-    const int KV = post_vec_len(K);
-    double *sth = vec + KV;       // word tiles + assembly: stable_softmax(eta~) (stm.py:998,1083) ...
-    double *sdv = vec + KV;       // ... bound: eta - mu broadcast (dense siginv only)
+    const int K = P.K, n = P.n, nm1 = n - 1;
+    const PostLds LM = post_lds_map(K, NB);
+    const int CP = (K + 1) >> 1, MDUMP = LM.mdump;   // CP: chunks of a row that hold topics
+    constexpr int TILE = TW * PITCH + 8;   // doubles per tile buffer (post_lds_map)
+    double *M = post_lds;            // row-packed lower triangle (after the word loop)
+    double *wpar = post_lds + LM.wpar, *sex = post_lds + LM.sex, *eth = post_lds + LM.eth;
+    double *vec = post_lds + LM.vec;
+    double *sth = vec;               // word loop .. PD ladder: stable_softmax(eta~) (stm.py:998,1083)
+    double *sdv = vec;               // bound: eta - mu broadcast (dense siginv only)
+    double *srd = vec;               // inverse: 1 / diag(L)
     const double *S = P.siginv;
-    double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
+    const bool sdiag = P.siginv_diag != 0;
+    double *sig_acc = P.sigma_part + (size_t)blockIdx.x * (size_t)(NBC * (NBC + 1) / 2) * 4 * WAVE;   // this workgroup's own sum of nu, tile layout
     bool isn = lane < n, isk = lane < K;
     int fr = lane & 15, fq = lane >> 4;  // MFMA fragment coordinates
     // The lane id is re-read behind an opaque move at the start of every phase: otherwise the lane-dependent LDS
-    // addresses of the unrolled tile code are hoisted out of the document loop as invariants and live in scratch memory.
+    // addresses of the unrolled code are hoisted out of the document loop as invariants and live in scratch memory.
     auto relane = [&]() __attribute__((always_inline)) {
         int l = threadIdx.x;
         asm volatile("" : "+v"(l));
         lane = l; isn = l < n; isk = l < K; fr = l & 15; fq = l >> 4;
     };
-
-    v4d acc_nu[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc_nu[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    double nu_rem = 0.0;   // REM: running sum of nu[lane][R0]
+    auto RS = [](int i) __attribute__((always_inline)) { return tri_row(i); };
+    const unsigned K8 = 8u * (unsigned)K;
 
     for (int64_t tk = blockIdx.x; tk < P.count; tk += gridDim.x) {
         relane();
-        if (P.debug_flags & 16) {   // nothing may depend on what an earlier document or kernel left in the LDS
+        if (DBG && (P.debug_flags & 16)) {   // nothing may depend on what an earlier document or kernel left in the LDS
             STM_POST_SYNC();
             for (int q = lane; q < P.lds_doubles; q += WAVE) post_lds[q] = __builtin_nan("");
             STM_POST_SYNC();
@@ -148,10 +133,59 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         const int Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
         const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
-        double *bssT = P.beta_ssT + (size_t)asp * (size_t)P.V * K;
-        const bool dump_phi = P.phi_out && doc == P.phi_doc;
         long long tp[8];
-        tp[0] = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+        if (DBG) tp[0] = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+
+        // word ids (lane w < 16: word t0 + w) and counts (lane 4 w + q: word t0 + w) of a tile; lanes beyond the document
+        // repeat its last word (a valid row for the fetch)
+        auto load_ids = [&](int t0, int &idx, double &c) __attribute__((always_inline)) {
+            const int wi = t0 + lane, wc = t0 + (lane >> 2), last = Nd - 1;
+            idx = P.indices[p0 + (wi < last ? wi : last)];
+            c = P.counts[p0 + (wc < last ? wc : last)];   // masked where it is used: a select here would wait for the load at once
+        };
+        // the 16 rows of a tile, betaT -> LDS: chunk c = 64 q + lane (16 bytes) is chunk c mod PC of word c / PC.  Chunks
+        // beyond the topics of a row (K below this instantiation's maximum) repeat its last one: finite, and the sums
+        // meet them with zeros.  All word ids first (one round trip through the crossbar), then the fetches back to back.
+        auto tile_fetch = [&](int idxv, int buf) __attribute__((always_inline)) {
+            unsigned off[NQ];
+            int id[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = 64 * q + lane;
+                int w = (int)(((unsigned)c * (65536u / PC + 1u)) >> 16);      // c / PC for c < 1024 (PC <= 33)
+                int o = c - (int)__umul24((unsigned)w, (unsigned)PC);
+                w = w < TW ? w : TW - 1;
+                o = o < CP ? o : CP - 1;
+                id[q] = __builtin_amdgcn_ds_bpermute(4 * w, idxv);
+                off[q] = 16u * (unsigned)o;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) off[q] += __umul24((unsigned)id[q], K8);
+            // Hand-written, so that the compiler does not know these loads write the LDS: it would make every LDS read
+            // behind them wait for ALL memory operations in flight (it cannot tell the two tile buffers apart) -- the wait
+            // that matters is the counted one at the top of the tile loop.  M0 carries the LDS destination (saved and
+            // restored: the compiler owns it); the last instruction moves the tile's last 16 chunks (exec = lanes 0..15).
+            const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(post_lds + buf * TILE);
+            unsigned keep;
+            unsigned long long ex;
+            static_assert(TW * PC - 64 * (NQ - 1) == 16, "the last fetch instruction covers 16 chunks");
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 1 < NQ)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(off[q]), "s"(lds0 + 1024u * q), "s"(bT) : "memory");
+                else
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, 0xffff\n\t"
+                                 "global_load_lds_dwordx4 %2, %4\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep), "=&s"(ex) : "v"(off[q]), "s"(lds0 + 1024u * q), "s"(bT) : "memory");
+            }
+        };
+
+        int idx0, idx1;
+        double c0, c1;
+        load_ids(0, idx0, c0);
+        load_ids(TW, idx1, c1);
 
         // ---- eta~, theta (unshifted softmax, stm.py:547-549), stable softmax, exp(eta~)
         const double eta_i = isn ? P.eta[doc * n + lane] : 0.0;  // lane K-1 holds the appended 0
@@ -163,380 +197,339 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         const double es = isk ? exp(eta_i - m) : 0.0;
         const double ssum = wave_sum(es);
         const double ths = es / ssum;
-        STM_POST_SYNC();  // the previous document's readers of M / vec are done
-        if (lane < KV) {
-            sex[lane] = ex;
-            sth[lane] = isk ? ths : 0.0;
+        STM_POST_SYNC();  // the previous document's readers of region 0 / vec are done (one wave: the LDS works in order)
+        wait_lds();
+        if (lane < 8 * QP) {
+            sex[lane] = ex;                         // zeros from K on
+            eth[lane] = isk ? ex * ths : 0.0;       // theta . (beta * exp(eta~)) = sum_k beta_k (exp(eta~)_k theta_k), stm.py:1088-1094
         }
-        // topic rows K..63 of T stay zero for the whole document
-        for (int q = lane; q < PT * TLD; q += WAVE) T[q] = 0.0;
-        STM_POST_SYNC();
+        if (8 * QP > WAVE && lane + WAVE < 8 * QP) { sex[lane + WAVE] = 0.0; eth[lane + WAVE] = 0.0; }
+        if (lane < 16) post_lds[(lane >> 3) * TILE + TW * PITCH + (lane & 7)] = 0.0;   // the pads behind both tile buffers
+        tile_fetch(idx0, 0);
 
-        if (P.prof) tp[1] = (long long)__builtin_readcyclecounter();
-        relane();
+        if (DBG && P.prof) tp[1] = (long long)__builtin_readcyclecounter();
         double csum = 0.0, ll = 0.0, rowc = 0.0;
-        bool bad = false;
+        bool sbad = false;
         v4d acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
         double hrem = 0.0;   // REM: (b b^T)[lane][R0]
-        const int kc = (K + 3) >> 2;  // topics per quarter in step 2
         long long tq[4] = {0, 0, 0, 0};
 
-        // Software pipeline over the tiles: while tile t is reduced / scattered / multiplied, the beta rows
-        // of tile t+1 are already in flight (into the registers the LDS transpose of tile t has just
-        // released) and the word ids / counts of tile t+2 are being fetched.
-        auto load_ids = [&](int t0, int &idx, double &c) __attribute__((always_inline)) {
-            const bool in = t0 + lane < Nd && lane < TW;
-            idx = in ? P.indices[p0 + t0 + lane] : 0;
-            c = in ? P.counts[p0 + t0 + lane] : 0.0;
-        };
-        double g[TW];
-        auto load_rows = [&](int t0, int idx_l) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < TW; ++j) {
-                const int idx = __builtin_amdgcn_readlane(idx_l, j);
-                g[j] = (isk && t0 + j < Nd) ? bT[(size_t)idx * K + lane] : 0.0;
-            }
-        };
-        int my_idx, idx1;
-        double my_c, c1;
-        load_ids(0, my_idx, my_c);
-        load_ids(TW, idx1, c1);
-        load_rows(0, my_idx);
-        for (int t0 = 0; t0 < Nd; t0 += TW) {
+        const bool dump_phi = P.phi_out && doc == P.phi_doc;
+        for (int t0 = 0, buf = 0; t0 < Nd; t0 += TW, buf ^= 1) {
             const int nw = Nd - t0 < TW ? Nd - t0 : TW;
-            long long c0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-            // -- 1. the tile's 16 coalesced rows (issued one tile ago), transposed into T[topic][word]
-            if (isk) {
-                double2 *row = reinterpret_cast<double2 *>(T + (size_t)lane * TLD);
-#pragma unroll
-                for (int j = 0; j < TW; j += 2) row[j >> 1] = make_double2(g[j], g[j + 1]);
-            }
+            long long cy0 = (DBG && P.prof) ? (long long)__builtin_readcyclecounter() : 0;
+            relane();
+            // The tile (fetched a whole tile ago) and the word ids have landed; nothing slow is in flight behind them -- this
+            // kernel issues no atomics.
+            wait_vmem();
+            STM_POST_SYNC();
+            double *T = post_lds + buf * TILE;
+            if (t0 + TW < Nd) tile_fetch(idx1, buf ^ 1);   // the other buffer's readers finished a tile ago
             int idx2;
             double c2;
-            if (t0 + TW < Nd) load_rows(t0 + TW, idx1);
-            load_ids(t0 + 2 * TW, idx2, c2);
-            STM_POST_SYNC();
-            if (P.prof) { const long long c1 = __builtin_readcyclecounter(); tq[0] += c1 - c0; c0 = c1; }
-            // -- 2. per-word sums, lane = (word fr, topic quarter fq)
+            load_ids(t0 + 2 * TW, idx2, c2);              // plain loads: the compiler waits for them where they are first read
+            if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[0] += cy - cy0; cy0 = cy; }
+            // -- 1. per-word sums, lane = (word lane >> 2, quarter lane & 3 of the row; zeros of sex / eth from K on)
             {
-                double Sp = 0.0, Lp = 0.0;
-                const int k0 = fq * kc;
-#pragma unroll 4
-                for (int kk = 0; kk < kc; ++kk) {
-                    const int k = k0 + kk;
-                    const double a = T[(size_t)k * TLD + fr] * sex[k];
-                    Sp += a;              // np.sum(a, 0)
-                    Lp += sth[k] * a;     // theta @ (beta * exp(eta~)), stm.py:1088-1094
+                const int w = lane >> 2, q = lane & 3;
+                const double2 *T2 = reinterpret_cast<const double2 *>(T) + w * PC + q * QP;
+                const double2 *E2 = reinterpret_cast<const double2 *>(sex) + q * QP;
+                const double2 *H2 = reinterpret_cast<const double2 *>(eth) + q * QP;
+                double sx = 0.0, sy = 0.0, lx = 0.0, ly = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < QP; ++kk) {
+                    const double2 t = T2[kk], e = E2[kk], h = H2[kk];
+                    sx = fma(t.x, e.x, sx); sy = fma(t.y, e.y, sy);    // np.sum(a, 0), a = beta * exp(eta~)
+                    lx = fma(t.x, h.x, lx); ly = fma(t.y, h.y, ly);    // theta @ a
                 }
-                Sp += __shfl_xor(Sp, 16); Sp += __shfl_xor(Sp, 32);
-                Lp += __shfl_xor(Lp, 16); Lp += __shfl_xor(Lp, 32);
-                if (lane < TW) {   // quarter 0 owns the word; words beyond the document get { 0, 0 }
-                    double wq = 0.0, sq = 0.0;
-                    if (lane < nw) {
-                        const double c = my_c;
-                        sq = sqrt(c);
-                        ll += log_pos(Lp) * c;
-                        csum += c;
-                        wq = sq / Sp;     // sqrt(c) / colsum: update_z, stm.py:1115, and the factor of b, stm.py:1001
-                    }
-                    *reinterpret_cast<double2 *>(wpar + 2 * lane) = make_double2(wq, sq);
-                }
+                double Sw = sx + sy, Lw = lx + ly;
+                Sw += dpp_move<DPP_XOR1>(Sw); Sw += dpp_move<DPP_XOR2>(Sw);
+                Lw += dpp_move<DPP_XOR1>(Lw); Lw += dpp_move<DPP_XOR2>(Lw);
+                const bool valid = w < nw, own = q == 0;
+                const double c = valid ? c0 : 0.0, sq = sqrt(c);
+                const double wq = valid ? sq / Sw : 0.0;   // sqrt(c) / colsum: update_z, stm.py:1115, and the factor of b, stm.py:1001
+                const double lg = log_pos(Lw) * c;
+                ll += (valid && own) ? lg : 0.0;
+                csum += own ? c : 0.0;
+                if (own) *reinterpret_cast<double2 *>(wpar + 2 * w) = make_double2(wq, sq);
+                // phi = beta * theta * r (stm_betass.h): r = exp-sum * c / S, in update_z's association (sqrt(c) / S) * sqrt(c).
+                // assert np.all(phi >= 0) (stm.py:1117) fails exactly when a column sum is 0 (0 * inf), infinite or NaN.
+                if (valid && own) P.rw[p0 + t0 + w] = (wq * sq) * sumex;
+                sbad |= valid && !(Sw > 0.0 && Sw < INFINITY);
             }
             STM_POST_SYNC();
-            if (P.prof) { const long long c1 = __builtin_readcyclecounter(); tq[1] += c1 - c0; c0 = c1; }
-            // -- 3. scatter phi, rowsum(c'), T <- b (lane = topic)
+            if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[1] += cy - cy0; cy0 = cy; }
+            // -- 2. rowsum(c'), T <- b (lane = topic).  b = a * (sqrt(c) / S) serves both the Hessian (stm.py:1001, which
+            // divides a * sqrt(c) by S: <= 1.5 ulp apart) and phi = b * sqrt(c) (stm.py:1115-1116, this order); rowsum(c') of
+            // stm.py:1002,1011 is the row sum of that same product.  Four words per round, their LDS reads in flight
+            // together.  Words beyond the document carry sqrt(c) / S = 0: b = 0.  (phi itself goes to beta_ss in
+            // stm_betass.h's word-major pass.)
             if (isk) {
-                double *trow = T + (size_t)lane * TLD;
-                // four words per round, their LDS traffic in 16-byte pieces; columns beyond the document hold
-                // zeros and get zeros back.  b = a * (sqrt(c) / S) serves both the Hessian (stm.py:1001, which
-                // divides a * sqrt(c) by S: <= 1.5 ulp apart) and phi = b * sqrt(c) (stm.py:1115-1116, this order);
-                // rowsum(c') of stm.py:1002,1011 is the row sum of that same product.
-                auto round4 = [&](int j0, auto fullc) __attribute__((always_inline)) {
-                    double2 *tp2 = reinterpret_cast<double2 *>(trow + j0);
-                    const double2 ta = tp2[0], tb = tp2[1];
-                    const double2 *wp2 = reinterpret_cast<const double2 *>(wpar + 2 * j0);
-                    const double2 w0 = wp2[0], w1 = wp2[1], w2 = wp2[2], w3 = wp2[3];   // { sqrt(c) / S, sqrt(c) }
-                    const double b0 = (ta.x * ex) * w0.x, b1 = (ta.y * ex) * w1.x;
-                    const double b2 = (tb.x * ex) * w2.x, b3 = (tb.y * ex) * w3.x;
-                    const double ph[4] = {b0 * w0.y, b1 * w1.y, b2 * w2.y, b3 * w3.y};
-                    tp2[0] = make_double2(b0, b1);
-                    tp2[1] = make_double2(b2, b3);
-                    rowc += ph[0]; rowc += ph[1]; rowc += ph[2]; rowc += ph[3];
-                    bad |= !(ph[0] >= 0.0) | !(ph[1] >= 0.0) | !(ph[2] >= 0.0) | !(ph[3] >= 0.0);
+                double *tc = T + lane;
+                const double2 *wp2 = reinterpret_cast<const double2 *>(wpar);
+#pragma unroll
+                for (int w0 = 0; w0 < TW; w0 += 4) {
+                    double t[4];
+                    double2 wp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { t[u] = tc[(w0 + u) * PITCH]; wp[u] = wp2[w0 + u]; }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int j = j0 + u;
-                        if (decltype(fullc)::value || j < nw) {   // uniform
-                            const int idx = __builtin_amdgcn_readlane(my_idx, j);
-                            if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + lane, ph[u]);  // stm.py:588
-                            if (dump_phi) P.phi_out[(size_t)lane * Nd + t0 + j] = ph[u];
-                        }
+                        const double b = (t[u] * ex) * wp[u].x;
+                        const double ph = b * wp[u].y;
+                        tc[(w0 + u) * PITCH] = b;
+                        rowc += ph;
                     }
-                };
-                if (nw == TW) {   // a full tile: the four rounds in one straight line, their LDS reads in flight together
-#pragma unroll
-                    for (int j0 = 0; j0 < TW; j0 += 4) round4(j0, std::true_type{});
-                } else {
-                    for (int j0 = 0; j0 < nw; j0 += 4) round4(j0, std::false_type{});
                 }
             }
             STM_POST_SYNC();
-            if (P.prof) { const long long c1 = __builtin_readcyclecounter(); tq[2] += c1 - c0; c0 = c1; }
-            // -- 4. b b^T on the matrix cores, upper block triangle
-            if (!(P.debug_flags & 2)) {
+            if (dump_phi && isk)   // the reference keeps the last document's phi (stm.py:1116)
+                for (int w = 0; w < nw; ++w) P.phi_out[(size_t)lane * Nd + t0 + w] = T[w * PITCH + lane] * wpar[2 * w + 1];
+            if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[2] += cy - cy0; cy0 = cy; }
+            // -- 3. b b^T on the matrix cores, upper block triangle
+            {
+                const double *tr = T + fq * PITCH + fr;
+                double f[TW / 4][NB];
+#pragma unroll
+                for (int s = 0; s < TW / 4; ++s)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) f[s][b] = tr[4 * s * PITCH + 16 * b];
 #pragma unroll
                 for (int s = 0; s < TW / 4; ++s) {
-                    double f[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) f[b] = T[(size_t)(b * 16 + fr) * TLD + s * 4 + fq];
                     int t = 0;
 #pragma unroll
                     for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                         for (int bj = bi; bj < NB; ++bj, ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][bi], f[s][bj], acc[t], 0, 0, 0);
                 }
-                if (REM && isn) {
-                    const double2 *own = reinterpret_cast<const double2 *>(T + (size_t)lane * TLD);
-                    const double2 *rem = reinterpret_cast<const double2 *>(T + (size_t)R0 * TLD);
+                if (REM) {
+                    const double *own = T + (lane < PITCH ? lane : 0), *rem = T + R0;
                     double h0 = 0.0, h1 = 0.0;
 #pragma unroll
-                    for (int w = 0; w < TW / 2; ++w) {
-                        const double2 a = own[w], b = rem[w];
-                        h0 = fma(a.x, b.x, h0);
-                        h1 = fma(a.y, b.y, h1);
+                    for (int w = 0; w < TW; w += 2) {
+                        h0 = fma(own[w * PITCH], rem[w * PITCH], h0);
+                        h1 = fma(own[(w + 1) * PITCH], rem[(w + 1) * PITCH], h1);
                     }
                     hrem += h0 + h1;
                 }
             }
             STM_POST_SYNC();
-            if (P.prof) { const long long c1t = __builtin_readcyclecounter(); tq[3] += c1t - c0; }
-            my_idx = idx1; my_c = c1; idx1 = idx2; c1 = c2;
+            wait_lds();         // every read of this buffer has returned before the tile after next is fetched into it
+            if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[3] += cy - cy0; }
+            idx0 = idx1; c0 = c1; idx1 = idx2; c1 = c2;
         }
-        if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
-        if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
+        STM_POST_SYNC();
+        sth[lane] = isk ? ths : 0.0;   // inside region 0, behind the matrix: the tiles are done
+        if (DBG && P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
+        if (DBG && P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         relane();
-        if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
+        if (wave_any(sbad || (isk && !(rowc >= 0.0)))) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);   // stm.py:1117
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
 
-        // ---- assemble H = b b^T - N theta theta^T, diag += -rowsum(c') + N theta, [:-1,:-1] + siginv:
-        // the MFMA tiles go to LDS raw, then lane i finishes row i (keeps the 4*NT tile elements
-        // from being in flight at once)
-        {
+        // ---- H = b b^T - N theta theta^T (+ siginv off the diagonal), from the accumulator tiles into the packed lower
+        // triangle: element (i, j), i <= j, of the upper block triangle is stored as M[j][i].  The diagonal cells get the raw
+        // b b^T - N theta^2; the lane that owns row i turns it into diagA below.  Run again (same registers, same
+        // operations, same bits) when a failed factorisation has eaten the matrix.
+        auto assemble = [&]() __attribute__((always_inline)) {
             int t = 0;
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
-                for (int bj = bi; bj < NB; ++bj, ++t)
+                for (int bj = bi; bj < NB; ++bj, ++t) {
+                    const int j = bj * 16 + fr, jc = j < n ? j : nm1;
+                    const double thj = sth[jc];
+                    const int rsj = RS(jc);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
-                        if (i < n && j < n) {
-                            M[(size_t)i * MLD + j] = acc[t][r];
-                            if (bi != bj) M[(size_t)j * MLD + i] = acc[t][r];
-                        }
+                        const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : nm1;
+                        double h = acc[t][r] - Ndoc * (sth[ic] * thj);
+                        if (!sdiag && i != j) h += S[(size_t)ic * n + jc];
+                        const bool st = j < n && (bi != bj || i <= j);
+                        M[st ? rsj + i : MDUMP] = h;
                     }
-            if (REM && isn) {
-                M[(size_t)lane * MLD + R0] = hrem;
-                M[(size_t)R0 * MLD + lane] = hrem;
+                }
+            if (REM) {
+                const int ic = isn ? lane : nm1;
+                double h = hrem - Ndoc * (sth[ic] * sth[R0]);
+                if (!sdiag && lane != R0) h += S[(size_t)R0 * n + ic];
+                M[isn ? RS(R0) + lane : MDUMP] = h;
             }
-        }
-        STM_POST_SYNC();
-        if (isn) {
-            double *mi = M + (size_t)lane * MLD;
-            const double thi = sth[lane];
-            if (P.siginv_diag) {   // what stm.py:501 produces: only the diagonal of siginv is non-zero
-                const double sii = S[(size_t)lane * n + lane];
-                double2 *mi2 = reinterpret_cast<double2 *>(mi);
-                const double2 *th2 = reinterpret_cast<const double2 *>(sth);
-                int j = 0;
-#pragma unroll 2
-                for (; j + 1 < n; j += 2) {
-                    const double2 mv = mi2[j >> 1], tv = th2[j >> 1];
-                    double h0 = mv.x - Ndoc * (thi * tv.x), h1 = mv.y - Ndoc * (thi * tv.y);
-                    if (j == lane) h0 = (h0 - rowc + Ndoc * thi) + sii;
-                    if (j + 1 == lane) h1 = (h1 - rowc + Ndoc * thi) + sii;
-                    mi2[j >> 1] = make_double2(h0, h1);
-                }
-                if (j < n) {
-                    double h = mi[j] - Ndoc * (thi * sth[j]);
-                    if (j == lane) h = (h - rowc + Ndoc * thi) + sii;
-                    mi[j] = h;
-                }
-            } else {
-                for (int j = 0; j < n; ++j) {
-                    double h = mi[j] - Ndoc * (thi * sth[j]);
-                    if (j == lane) h = h - rowc + Ndoc * thi;
-                    mi[j] = h + S[(size_t)lane * n + j];
-                }
-            }
-        }
-        STM_POST_SYNC();
+        };
 
-        if (P.prof) tp[3] = (long long)__builtin_readcyclecounter();
-        relane();
-        // ---- PD handling.  diagA: current diagonal of A (lane i); off-diagonals of A are read
-        // from the upper triangle of M, which Cholesky never writes.
-        double diagA = isn ? M[(size_t)lane * MLD + lane] : 1.0;
-        double Ldiag = 1.0;
-        // np.linalg.cholesky; L strictly-lower into M, diagonal in Ldiag.  TWO columns per step: the dot
-        // products of columns j and j+1 against the finished columns share the loads of the lane's own row
-        // (3 LDS reads per 2 FMAs), column j+1's last term uses L[:, j] straight from registers
-        // (L[j+1][j] by v_readlane), and the serial per-column tail (pivot broadcast, sqrt, reciprocal,
-        // LDS hand-off) is paid once per pair.
-        auto cholesky = [&]() -> bool {
+        double diagA = 1.0, Ldiag = 1.0;
+        bool clean = false;
+        long long tcc[4] = {0, 0, 0, 0};
+        // np.linalg.cholesky, blocked by 16 columns and in place of the packed triangle.  Per panel: (a) the block column
+        // minus the products of the finished panels on the matrix cores; (b) the panel with lane i holding row i's 16
+        // entries in registers, right-looking and free of branches on the data -- a failed pivot only raises a flag, and
+        // what the remaining columns compute from it is never stored -- so the updates of the later columns fill the
+        // latency of the pivot's rsq + Goldschmidt chain; finished entries of row J come from lane J by v_readlane.
+        auto cholesky = [&]() __attribute__((always_inline)) -> bool {
             // a pivot never exceeds its diagonal entry (what is subtracted from it are squares, in floating point too): an
             // entry <= 0 (or NaN) fails some pivot test for certain, and the attempt is decided without factorising
             if (wave_any(isn && !(diagA > 0.0))) return false;
-            bool ok = true;
-            int j = 0;
-            for (; j + 1 < n; j += 2) {
-                double tA = 0.0, tB = 0.0;
-                if (isn && lane >= j) {
-                    const double *ri = M + (size_t)lane * MLD, *rj = M + (size_t)j * MLD, *rk = rj + MLD;
-                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-                    int l = 0;
-                    for (; l + 7 < j; l += 8) {   // twelve 16-byte LDS reads in flight per round (rows are 16-byte aligned)
-                        double2 xv[4], pv[4], qv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            xv[u] = *reinterpret_cast<const double2 *>(ri + l + 2 * u);
-                            pv[u] = *reinterpret_cast<const double2 *>(rj + l + 2 * u);
-                            qv[u] = *reinterpret_cast<const double2 *>(rk + l + 2 * u);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            a0 = fma(xv[u].x, pv[u].x, a0); b0 = fma(xv[u].x, qv[u].x, b0);
-                            a1 = fma(xv[u].y, pv[u].y, a1); b1 = fma(xv[u].y, qv[u].y, b1);
-                        }
-                    }
-                    for (; l + 3 < j; l += 4) {   // six 16-byte LDS reads in flight per round
-                        const double2 xa = *reinterpret_cast<const double2 *>(ri + l), xb = *reinterpret_cast<const double2 *>(ri + l + 2);
-                        const double2 pa = *reinterpret_cast<const double2 *>(rj + l), pb = *reinterpret_cast<const double2 *>(rj + l + 2);
-                        const double2 qa = *reinterpret_cast<const double2 *>(rk + l), qb = *reinterpret_cast<const double2 *>(rk + l + 2);
-                        a0 = fma(xa.x, pa.x, a0); b0 = fma(xa.x, qa.x, b0);
-                        a1 = fma(xa.y, pa.y, a1); b1 = fma(xa.y, qa.y, b1);
-                        a0 = fma(xb.x, pb.x, a0); b0 = fma(xb.x, qb.x, b0);
-                        a1 = fma(xb.y, pb.y, a1); b1 = fma(xb.y, qb.y, b1);
-                    }
-                    for (; l + 1 < j; l += 2) {
-                        const double x0 = ri[l], x1 = ri[l + 1];
-                        a0 = fma(x0, rj[l], a0);
-                        b0 = fma(x0, rk[l], b0);
-                        a1 = fma(x1, rj[l + 1], a1);
-                        b1 = fma(x1, rk[l + 1], b1);
-                    }
-                    if (l < j) {
-                        const double x0 = ri[l];
-                        a0 = fma(x0, rj[l], a0);
-                        b0 = fma(x0, rk[l], b0);
-                    }
-                    tA = ((lane == j) ? diagA : rj[lane]) - (a0 + a1);               // A[lane][j] - ...
-                    if (lane > j) tB = ((lane == j + 1) ? diagA : rk[lane]) - (b0 + b1);
-                }
-                const double dA = lane_bcast(tA, j);
-                if (!(dA > PIVOT_TOL * lane_bcast(diagA, j))) { ok = false; break; }   // see PIVOT_TOL
-                double ljj, rjj;                // LAPACK dpotf2 scales the column by the reciprocal as well
-                sqrt_and_rsqrt(dA, ljj, rjj);
-                const double lA = (isn && lane > j) ? tA * rjj : 0.0;             // L[lane][j]
-                tB -= lA * lane_bcast(lA, j + 1);                                 // ... - L[lane][j] L[j+1][j]
-                const double dB = lane_bcast(tB, j + 1);
-                if (lane == j) Ldiag = ljj;
-                if (isn && lane > j) M[(size_t)lane * MLD + j] = lA;
-                if (!(dB > PIVOT_TOL * lane_bcast(diagA, j + 1))) { ok = false; break; }
-                double lkk, rkk;
-                sqrt_and_rsqrt(dB, lkk, rkk);
-                if (lane == j + 1) Ldiag = lkk;
-                if (isn && lane > j + 1) M[(size_t)lane * MLD + j + 1] = tB * rkk;
-                STM_POST_SYNC();
-            }
-            if (ok && j < n) {   // odd n: the last column on its own
-                double t = 0.0;
-                if (lane == j) {
-                    const double *ri = M + (size_t)lane * MLD;
-                    double a0 = 0.0;
-                    for (int l = 0; l < j; ++l) a0 = fma(ri[l], ri[l], a0);
-                    t = diagA - a0;
-                }
-                const double d = lane_bcast(t, j);
-                if (!(d > PIVOT_TOL * lane_bcast(diagA, j))) ok = false;
-                else if (lane == j) Ldiag = sqrt(d);
-            }
+            clean = false;
+            if (isn) M[RS(lane) + lane] = diagA;
             STM_POST_SYNC();
+            bool ok = true;
+#pragma unroll 1
+            for (int p = 0; p < NBC && ok; ++p) {
+                const int J0 = 16 * p;
+                relane();
+                long long cq = (DBG && P.prof) ? (long long)__builtin_readcyclecounter() : 0;
+                if (p > 0) {
+                    const int bc = J0 + fr, bcc = bc < n ? bc : nm1;
+                    const double *brow = M + RS(bcc);                       // row of L_p* for the B operands (L_pk^T)
+#pragma unroll 1
+                    for (int bi = p; bi < NBC; ++bi) {
+                        const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
+                        const double *arow = M + RS(arc);
+                        int dst[4];
+                        double old[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = bi * 16 + fq + 4 * r;
+                            dst[r] = (i >= bc && i < n) ? RS(i) + bc : MDUMP;   // lower triangle incl. the diagonal (bc <= i < n)
+                            old[r] = M[dst[r]];
+                        }
+                        v4d a = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                        for (int k = 0; k < p; ++k) {
+                            double av[4], bv[4];
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) {
+                                const int kk = k * 16 + 4 * sk + fq;
+                                av[sk] = arow[kk]; bv[sk] = brow[kk];
+                            }
+#pragma unroll
+                            for (int sk = 0; sk < 4; ++sk) a = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sk], bv[sk], a, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) M[dst[r]] = old[r] - a[r];
+                    }
+                    STM_POST_SYNC();
+                }
+                if (DBG && P.prof) { const long long c1 = __builtin_readcyclecounter(); tcc[0] += c1 - cq; cq = c1; }
+                // (b) rows above the panel shadow its first row, rows beyond n the last one (never stored)
+                const int ic = lane < J0 ? J0 : (isn ? lane : nm1);
+                const double2 *wr = reinterpret_cast<const double2 *>(M + RS(ic) + J0);
+                double w[16];
+#pragma unroll
+                for (int c2 = 0; c2 < 8; ++c2) { const double2 t = wr[c2]; w[2 * c2] = t.x; w[2 * c2 + 1] = t.y; }
+                bool bad = false;
+                if (DBG && P.prof) { pin(w[0]); pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[1] += c1 - cq; cq = c1; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (J0 + j < n) {   // uniform
+                        const int J = J0 + j;
+                        const double d = lane_bcast(w[j], J);
+                        const double dA = lane_bcast(diagA, J);
+                        bad |= !(d > PIVOT_TOL * dA);           // see PIVOT_TOL
+                        double ljj, rjj;                        // LAPACK dpotf2 scales the column by the reciprocal as well
+                        sqrt_and_rsqrt(d, ljj, rjj);
+                        if (lane == J) Ldiag = ljj;
+                        w[j] *= rjj;
+#pragma unroll
+                        for (int c = j + 1; c < 16; ++c) {
+                            const double x = lane_bcast(w[j], (J0 + c) & 63);   // L[J0 + c][J]
+                            w[c] = fma(-w[j], x, w[c]);
+                        }
+                    }
+                }
+                if (DBG && P.prof) { pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[2] += c1 - cq; cq = c1; }
+                if (bad) { ok = false; break; }
+                // pairs (c, c + 1) with the first cell strictly below the diagonal; the second one is then at most the
+                // diagonal cell, which is free (it takes X's diagonal later)
+#pragma unroll
+                for (int c2 = 0; c2 < 8; ++c2) {
+                    const int c = 2 * c2;
+                    const bool st = isn && lane > J0 + c;
+                    *reinterpret_cast<double2 *>(M + (st ? RS(lane) + J0 + c : MDUMP)) = make_double2(w[c], w[c + 1]);
+                }
+                STM_POST_SYNC();
+                if (DBG && P.prof) { const long long c1 = __builtin_readcyclecounter(); tcc[3] += c1 - cq; }
+            }
             return ok;
         };
-        auto make_pd = [&]() {  // stm.py:964-984
+        auto make_pd = [&]() __attribute__((always_inline)) {  // stm.py:964-984; M holds A (clean)
             if (isn) {
                 double mag = 0.0;
+                const double *ri = M + RS(lane);
                 for (int j = 0; j < n; ++j) {
-                    const double aij = (j == lane) ? diagA
-                                     : (j > lane ? M[(size_t)lane * MLD + j] : M[(size_t)j * MLD + lane]);
+                    const double lo = ri[j < lane ? j : 0], up = M[RS(j) + (j > lane ? lane : 0)];
+                    const double aij = (j == lane) ? diagA : (j < lane ? lo : up);
                     mag += fabs(aij);
                 }
                 mag -= fabs(diagA);
                 if (diagA < mag) diagA = mag;
             }
         };
-        auto dump = [&](double *base, bool lower_L) {
-            if (!base) return;
-            double *o = base + (size_t)doc * n * n;
+        auto dump_hess = [&]() {
+            double *o = P.hess_out + (size_t)doc * n * n;
             if (isn)
-                for (int j = 0; j < n; ++j) {
-                    double val;
-                    if (lower_L) val = (j == lane) ? Ldiag : (j < lane ? M[(size_t)lane * MLD + j] : 0.0);
-                    else val = (j == lane) ? diagA
-                             : (j > lane ? M[(size_t)lane * MLD + j] : M[(size_t)j * MLD + lane]);
-                    o[(size_t)lane * n + j] = val;
-                }
+                for (int j = 0; j < n; ++j)
+                    o[(size_t)lane * n + j] = (j == lane) ? diagA : (j < lane ? M[RS(lane) + j] : M[RS(j) + lane]);
         };
-        // One Cholesky site for every stage of the reference's PD ladder (five inlined copies put
-        // the fallback ones on cold paths, where the register allocator parks its spill reloads):
+
+        // One assembly site and one Cholesky site for every stage of the reference's PD ladder:
         //   0 hessian(): PD test as Cholesky success (stm.py:1017)   1 after make_pd (stm.py:1019-1020)
         //   2 +1e-5 (stm.py:1021), decompose_hessian's np.linalg.cholesky (stm.py:1040)
         //   3 after make_pd (stm.py:1043)   4 scipy cholesky (UPPER) of make_pd(H) + 1e-5 I (stm.py:1046-1048)
         int path = 0;
         bool upper = false, fail = false;
         double keep = 0.0;
+        STM_POST_SYNC();
         for (int attempt = 0;; ++attempt) {
-            if (DUMP && attempt == 2) dump(P.hess_out, false);
-            const bool ok = (attempt == 0 && (P.debug_flags & 8)) ? true : cholesky();
-            if (attempt == 4) { diagA = keep; upper = true; fail = !ok; break; }
-            if (ok) {
-                if (DUMP && attempt < 2) dump(P.hess_out, false);
-                break;
+            relane();
+            if (!clean) {
+                assemble();
+                STM_POST_SYNC();
+                clean = true;
+                if (attempt == 0 && isn) {
+                    const double sii = S[(size_t)lane * n + lane];
+                    diagA = ((M[RS(lane) + lane] - rowc) + Ndoc * ths) + sii;   // stm.py:1003-1013, in this order
+                }
+                if (DBG && P.prof && attempt == 0) tp[3] = (long long)__builtin_readcyclecounter();
             }
-            if (attempt == 0) { make_pd(); path = 1; }
-            else if (attempt == 1) { if (isn) diagA += 1e-5; path = 2; }
-            else if (attempt == 2) { make_pd(); }
-            else { make_pd(); keep = diagA; if (isn) diagA += 1e-5; }
+            // what the previous, failed attempt asks for
+            if (attempt == 1) { make_pd(); path = 1; }
+            else if (attempt == 2) { if (isn) diagA += 1e-5; path = 2; }
+            else if (attempt == 3) { make_pd(); }
+            else if (attempt == 4) { make_pd(); keep = diagA; if (isn) diagA += 1e-5; }
+            if (DBG && P.hess_out && attempt <= 2) dump_hess();
+            const bool ok = cholesky();
+            if (attempt == 4) { diagA = keep; upper = true; fail = !ok; break; }
+            if (ok) break;
         }
         if (P.pd_path) P.pd_path[doc] = path;
         if (fail) {
             atomicMax(P.err_flag, 3 /* STM_ERR_LINALG */);
             continue;
         }
-        if (DUMP && P.chol_out) {
+        if (DBG && P.chol_out) {
             double *o = P.chol_out + (size_t)doc * n * n;
             if (isn)
                 for (int j = 0; j < n; ++j) {
-                    double val = (j == lane) ? Ldiag : (j < lane ? M[(size_t)lane * MLD + j] : 0.0);
+                    const double val = (j == lane) ? Ldiag : (j < lane ? M[RS(lane) + j] : 0.0);
                     if (upper) o[(size_t)j * n + lane] = val;  // the reference holds the upper factor here
                     else o[(size_t)lane * n + j] = val;
                 }
         }
 
-        if (P.prof) tp[4] = (long long)__builtin_readcyclecounter();
+        if (DBG && P.prof) tp[4] = (long long)__builtin_readcyclecounter();
         // ---- bound (stm.py:1068-1101)
         const double det = wave_sum(isn ? log(Ldiag) : 0.0);
         double q = 0.0;
         {
             const double d = eta_i - mu_i;
-            if (P.siginv_diag) {
+            if (sdiag) {
                 if (isn) q = (d * S[(size_t)lane * n + lane]) * d;
             } else {
+                STM_POST_SYNC();
                 if (isn) sdv[lane] = d;
                 STM_POST_SYNC();
                 if (isn) {
@@ -548,248 +541,214 @@ __global__ __launch_bounds__(64, STM_POST_WPE) void post_kernel(PostParams P) {
         }
         q = wave_sum(q);
         P.bound[doc] = ll + (-det) - 0.5 * q - P.sigmaentropy;  // uniform store
-        if (P.debug_flags & 4) continue;
 
-        if (P.prof) tp[5] = (long long)__builtin_readcyclecounter();
+        if (DBG && P.prof) tp[5] = (long long)__builtin_readcyclecounter();
         relane();
         // ---- nu = inv(triu(L^T)) inv(triu(L^T))^T (stm.py:1052-1066)
         const double Rdiag = 1.0 / Ldiag;
-        if (isn) srd[lane] = Rdiag;
         STM_POST_SYNC();
-        long long ti[4] = {0, 0, 0, 0};
-        if (P.prof) ti[0] = (long long)__builtin_readcyclecounter();
+        srd[lane] = isn ? Rdiag : 0.0;
+        STM_POST_SYNC();
+        long long ti[3] = {0, 0, 0};
+        if (DBG && P.prof) ti[0] = (long long)__builtin_readcyclecounter();
         if (!upper) {
-            // X = L^-1 (so that nu = X^T X), blocked by 16 and IN PLACE of L: lower triangle and diagonal of M.
-            // (I) the diagonal blocks, all at once, lane = (block, column c): X[i][c] = -(sum_{c<=l<i} L[i][l] X[l][c]) / L[i][i]
-            //     row by row and in place; a lane only ever reads back its own column, so the steps need no hand-off.
+            // X = L^-1 (so that nu = X^T X), blocked by 16 and IN PLACE of L (diagonal in the triangle's free diagonal cells).
+            // (I) all diagonal blocks at once, lane = (block, column c), the column in registers:
+            //     x[i] = X[i][c] = -(sum_{l<i} L[i][l] x[l]) / L[i][i]   (x[l] = 0 above the diagonal, x[c] = 1 / L[c][c]);
+            //     the rows of L are independent of x, so their loads run ahead of the substitution chain, and every store
+            //     comes after every load (one instruction stream, the LDS works in order).
             {
-                const int c = lane & 15, base = lane & ~15;
-                const int rows = n - base < 16 ? n - base : 16;    // rows of this lane's block (<= 0: no block)
-                const int rb = base < n ? base : 0;                 // lanes beyond the matrix shadow block 0 (nothing is stored)
-                const int rlast = (rows > 0 ? rows : 16) - 1;
-                double *xc = M + (size_t)rb * MLD + (base < n ? lane : c);   // X[rb + l][column]: the lane's own column, in place
-                if (base < n && c < rows) xc[(size_t)c * MLD] = srd[lane];  // X[c][c] = 1 / L[c][c]  (M's diagonal is free)
-                // every step fetches its whole row of L (broadcast per block) and the whole column of X in one batch --
-                // one LDS round trip per step -- and masks the terms outside [c, i)
-#pragma unroll 1
-                for (int i = 1; i < 16; ++i) {
-                    const int ir = i < rlast ? i : rlast;           // clamped: reads stay inside the matrix
-                    const double *lrow = M + (size_t)(rb + ir) * MLD + rb;
-                    double lv[16], xv[16];
+                const int c = lane & 15, rb = lane & ~15;
+                const bool has = rb < n;
+                const int rbc = has ? rb : 0;                         // lanes beyond the matrix shadow block 0 (nothing is stored)
+                const int rows = n - rbc < 16 ? n - rbc : 16;
+                const double2 *rd2 = reinterpret_cast<const double2 *>(srd + rbc);
+                // row rbc + i of the block starts at RS(rbc + i) + rbc = RS(rbc) + rbc + i rbc + RS(i) (rbc is even);
+                // rows beyond the matrix shadow the block's last row (their x is never stored)
+                const int base0 = RS(rbc) + rbc, lastoff = base0 + (rows - 1) * rbc + RS(rows - 1);
+                auto row_of = [&](int i) __attribute__((always_inline)) {
+                    return reinterpret_cast<const double2 *>(M + (i < rows ? base0 + i * rbc + tri_row(i) : lastoff));
+                };
+                double x[16];
+                double2 buf[2][8];   // the row after next is fetched while a row is consumed
+                x[0] = (c == 0) ? rd2[0].x : -0.0;
+                { const double2 *r1 = row_of(1); buf[1][0] = r1[0]; }
 #pragma unroll
-                    for (int l = 0; l < 16; l += 2) {
-                        const double2 t = *reinterpret_cast<const double2 *>(lrow + l);
-                        lv[l] = t.x; lv[l + 1] = t.y;
-                        xv[l] = xc[(size_t)(l < rlast ? l : rlast) * MLD];
-                        xv[l + 1] = xc[(size_t)(l + 1 < rlast ? l + 1 : rlast) * MLD];
+                for (int i = 1; i < 16; ++i) {
+                    if (i + 1 < 16) {
+                        const double2 *rn = row_of(i + 1);
+#pragma unroll
+                        for (int l2 = 0; 2 * l2 < i + 1; ++l2) buf[(i + 1) & 1][l2] = rn[l2];
                     }
-                    const double rd = srd[rb + ir];
+                    __builtin_amdgcn_sched_barrier(0);
                     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-                    for (int l = 0; l < 16; l += 2) {
-                        // both factors are selected: the row of L runs into columns nobody ever wrote (0 x NaN is NaN)
-                        const bool m0 = l >= c && l < i, m1 = l + 1 >= c && l + 1 < i;
-                        t0 = fma(m0 ? lv[l] : 0.0, m0 ? xv[l] : 0.0, t0);
-                        t1 = fma(m1 ? lv[l + 1] : 0.0, m1 ? xv[l + 1] : 0.0, t1);
+                    for (int l2 = 0; 2 * l2 < i; ++l2) {
+                        const double2 lv = buf[i & 1][l2];
+                        t0 = fma(lv.x, x[2 * l2], t0);
+                        if (2 * l2 + 1 < i) t1 = fma(lv.y, x[2 * l2 + 1], t1);
                     }
-                    // the row-i reads of every lane precede this store in the instruction stream; later steps read rows > i of L
-                    if (base < n && i > c && i < rows) xc[(size_t)i * MLD] = -(t0 + t1) * rd;
+                    const double2 rdp = rd2[i >> 1];
+                    const double rd = (i & 1) ? rdp.y : rdp.x;
+                    x[i] = (i == c) ? rd : -(t0 + t1) * rd;
+                    pin(x[i]);     // the substitution step stays between the two fetches (instruction selection would sink it)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool st = has && i >= c && i < rows;
+                    M[st ? base0 + i * rbc + tri_row(i) + c : MDUMP] = x[i];
                 }
             }
             STM_POST_SYNC();
-            if (P.prof) ti[1] = (long long)__builtin_readcyclecounter();
+            if (DBG && P.prof) ti[1] = (long long)__builtin_readcyclecounter();
             // (II) X_ij = -X_ii (sum_{j<=k<i} L_ik X_kj) on the matrix cores, block columns left to right, block rows
             //      top down (X_ij takes the place of L_ij, which no later product reads).  The inner sum comes out
             //      of the MFMA in exactly the register layout its B operand wants, so it never visits the LDS.
-            {
-                // runtime loops on purpose (the kernel lives at its VGPR budget): four fragment pairs in flight per step;
-                // loads are unconditional on clamped rows, masks are applied to the loaded values
-                const int nm1 = n - 1;
+            constexpr int NBI = REM ? NB : NBC;   // REM: the one row beyond the full blocks is done on the VALU, below
 #pragma unroll 1
-                for (int bj = 0; bj + 1 < NB; ++bj) {
+            for (int bj = 0; bj + 1 < NBI; ++bj) {
 #pragma unroll 1
-                    for (int bi = bj + 1; bi < NB; ++bi) {
-                        const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
-                        const double *arow = M + (size_t)arc * MLD;           // row of L_i* / X_ii for the A operands
-                        const int bc = bj * 16 + fr;
-                        v4d sacc = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int bi = bj + 1; bi < NBI; ++bi) {
+                    const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
+                    const double *arow = M + RS(arc);                     // row of L_i* / X_ii for the A operands
+                    const int bc = bj * 16 + fr;
+                    v4d sacc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-                        for (int k = bj; k < bi; ++k) {
-                            double av[4], bv[4];
-#pragma unroll
-                            for (int sk = 0; sk < 4; ++sk) {
-                                const int kk = k * 16 + 4 * sk + fq;           // < 16 (NB - 1) <= n: full blocks only
-                                av[sk] = arow[kk];                              // L_ik[fr][4 sk + fq]
-                                bv[sk] = M[(size_t)kk * MLD + bc];              // X_kj[4 sk + fq][fr]
-                            }
-#pragma unroll
-                            for (int sk = 0; sk < 4; ++sk) {
-                                const int kk = k * 16 + 4 * sk + fq;
-                                const double a = (ar < n) ? av[sk] : 0.0;
-                                const double bb = (k > bj || bc <= kk) ? bv[sk] : 0.0;   // the diagonal block of X is lower triangular
-                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, sacc, 0, 0, 0);
-                            }
-                        }
-                        double xv[4];
+                    for (int k = bj; k < bi; ++k) {
+                        double av[4], bv[4];
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) {
-                            const int ac = bi * 16 + 4 * sk + fq;
-                            xv[sk] = arow[ac < n ? ac : nm1];                   // X_ii[fr][4 sk + fq]
+                            const int kk = k * 16 + 4 * sk + fq;           // < 16 (NBC - 1) <= n: full blocks only
+                            av[sk] = arow[kk];                              // L_ik[fr][4 sk + fq]
+                            bv[sk] = M[RS(kk) + bc];                        // X_kj[4 sk + fq][fr]
                         }
-                        v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int sk = 0; sk < 4; ++sk) {
-                            const int ac = bi * 16 + 4 * sk + fq;
-                            const double a = (ac <= ar && ar < n) ? xv[sk] : 0.0;
-                            dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sacc[sk], dacc, 0, 0, 0);
+                            const int kk = k * 16 + 4 * sk + fq;
+                            const double a = (ar < n) ? av[sk] : 0.0;
+                            const double bb = (k > bj || bc <= kk) ? bv[sk] : 0.0;   // the diagonal block of X is lower triangular
+                            sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, sacc, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = bi * 16 + fq + 4 * r;
-                            if (row < n) M[(size_t)row * MLD + bc] = -dacc[r];
-                        }
-                        STM_POST_SYNC();
                     }
+                    double xv[4];
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) {
+                        const int ac = bi * 16 + 4 * sk + fq;
+                        xv[sk] = arow[ac < arc ? ac : arc];                 // X_ii[fr][4 sk + fq], at most the diagonal cell
+                    }
+                    v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int sk = 0; sk < 4; ++sk) {
+                        const int ac = bi * 16 + 4 * sk + fq;
+                        const double a = (ac <= ar && ar < n) ? xv[sk] : 0.0;
+                        dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sacc[sk], dacc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = bi * 16 + fq + 4 * r;
+                        M[row < n ? RS(row) + bc : MDUMP] = -dacc[r];
+                    }
+                    STM_POST_SYNC();
                 }
             }
-            if (P.prof) ti[2] = (long long)__builtin_readcyclecounter();
+            if (DBG && P.prof) ti[2] = (long long)__builtin_readcyclecounter();
             if (REM) {   // (III) the row beyond the blocks: X[R0][j] = -X[R0][R0] sum_{j<=k<R0} L[R0][k] X[k][j], lane = column j
                 double t[4] = {0.0, 0.0, 0.0, 0.0};
-                const double *lr = M + (size_t)R0 * MLD, *xc = M + (lane < R0 ? lane : 0);
+                const double2 *lr = reinterpret_cast<const double2 *>(M + RS(R0));
+                const int jc = lane < R0 ? lane : 0;
+#pragma unroll 1
                 for (int k = 0; k < R0; k += 8) {
-                    double lv[8], xv[8];
+                    double2 lv[4];
+                    double xv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { lv[u] = lr[k + u]; xv[u] = xc[(size_t)(k + u) * MLD]; }
+                    for (int u = 0; u < 4; ++u) lv[u] = lr[(k >> 1) + u];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u & 3] = fma(lv[u], (k + u >= lane) ? xv[u] : 0.0, t[u & 3]);
+                    for (int u = 0; u < 8; ++u) xv[u] = M[RS(k + u) + jc];   // above the diagonal: past the end of row k + u, selected away
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double l = (u & 1) ? lv[u >> 1].y : lv[u >> 1].x;
+                        t[u & 3] = fma(l, (k + u >= lane) ? xv[u] : 0.0, t[u & 3]);
+                    }
                 }
                 const double xr = -((t[0] + t[1]) + (t[2] + t[3])) * srd[R0];
-                if (lane < R0) M[(size_t)R0 * MLD + lane] = xr;   // after every lane's reads of row R0 (one instruction stream)
+                STM_POST_SYNC();
+                M[lane < R0 ? RS(R0) + lane : MDUMP] = xr;   // after every lane's reads of row R0 (one instruction stream)
             }
         }
         STM_POST_SYNC();
-        if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
+        if (DBG && P.prof) tp[6] = (long long)__builtin_readcyclecounter();
         relane();
-        if (P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = ti[2] - ti[1]; P.prof[doc * 40 + 30] = tp[6] - ti[2]; P.prof[doc * 40 + 31] = ti[0] - tp[5]; }
-        // nu = R R^T = X^T X on the matrix cores, accumulated straight into the workgroup's running sum
-        // (sigma_ss += nu, stm.py:582); fragment R[b*16 + fr][s4 + fq] = X[s4 + fq][b*16 + fr], zero below the diagonal
-        v4d nud[DUMP ? NT : 1];
-        if (DUMP) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { nud[t] = acc_nu[t]; acc_nu[t] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-        }
-        for (int s4 = 0; s4 < n; s4 += 4) {
-            const int col = s4 + fq;
-            double f[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int row = b * 16 + fr;
-                double v = 0.0;
-                if (row < n && col < n) {   // R[row][col] = X[col][row], X lower triangular with its diagonal in M
-                    if (upper) v = (col == row) ? srd[row] : 0.0;
-                    else if (col >= row) v = M[(size_t)col * MLD + row];
+        if (DBG && P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = ti[2] - ti[1]; P.prof[doc * 40 + 30] = tp[6] - ti[2]; P.prof[doc * 40 + 31] = ti[0] - tp[5]; }
+        // nu = R R^T = X^T X (sigma_ss += nu, stm.py:582), one block column bj of output tiles (bi <= bj) at a time on the
+        // matrix cores: nu[i][j] = sum_{l >= 16 bj} X[l][i] X[l][j] (X is lower triangular: rows above block bj add nothing);
+        // fragment X[s4 + fq][b*16 + fr], zero above the diagonal.  The workgroup's running sum lives in a slab of its own in
+        // the accumulators' register layout (tile (b, bj) at bj (bj + 1) / 2 + b, [r][lane]: every access one 512-byte
+        // run); its old values are fetched before the matrix-core loop they are added behind -- plain loads and stores,
+        // nobody else touches the slab.  Cells beyond n are exact zeros.  untile_sigma_kernel undoes the layout.
+        double *nu_doc = (DBG && P.nu_out) ? P.nu_out + (size_t)doc * n * n : nullptr;
+        if (upper) {   // nu = diag(1 / L_ii^2): element (i, i) sits in tile (b, b) at r = ((i & 15) - fq) / 4, lane = (fq, fr = i & 15)
+            for (int bb = 0; bb < NBC; ++bb) {
+                const int i = bb * 16 + fr, r = (fr - fq) >> 2;
+                if (((fr - fq) & 3) == 0 && fr >= fq && i < n) {
+                    const double v = srd[i] * srd[i];
+                    sig_acc[((size_t)(bb * (bb + 1) / 2 + bb) * 4 + r) * WAVE + lane] += v;
+                    if (DBG && nu_doc)
+                        for (int j = 0; j < n; ++j) nu_doc[(size_t)i * n + j] = (j == i) ? v : 0.0;
                 }
-                f[b] = v;
             }
-            int t = 0;
+        } else {
+#pragma unroll 1
+            for (int bj = 0; bj < NBC; ++bj) {
+                const int rj = bj * 16 + fr, rjc = rj < n ? rj : nm1;
+                double *slab = sig_acc + (size_t)(bj * (bj + 1) / 2) * 4 * WAVE + lane;
+                v4d an[NBC], old[NBC];
 #pragma unroll
-            for (int bi = 0; bi < NB; ++bi)
+                for (int b = 0; b < NBC; ++b) {
+                    an[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    if (b <= bj) {
 #pragma unroll
-                for (int bj = bi; bj < NB; ++bj, ++t)
-                    acc_nu[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc_nu[t], 0, 0, 0);
-        }
-        if (REM) {   // nu[i][R0] = R[i][R0] R[R0][R0]: R is upper triangular and R0 is its last row
-            double v = 0.0;
-            if (lane == R0) v = Rdiag * Rdiag;
-            else if (isn && !upper) v = M[(size_t)R0 * MLD + lane] * srd[R0];   // X[R0][lane] = R[lane][R0]
-            nu_rem += v;
-            if (DUMP && P.nu_out && isn) {
-                P.nu_out[(size_t)doc * n * n + (size_t)lane * n + R0] = v;
-                P.nu_out[(size_t)doc * n * n + (size_t)R0 * n + lane] = v;
-            }
-        }
-        if (DUMP) {  // parity-test build: per-document nu
-            int t = 0;
+                        for (int r = 0; r < 4; ++r) old[b][r] = slab[(b * 4 + r) * WAVE];
+                    }
+                }
+#pragma unroll 1
+                for (int s4 = bj * 16; s4 < n; s4 += 4) {
+                    const int col = s4 + fq, colc = col < n ? col : nm1;
+                    const double *xr = M + RS(colc);
+                    double f[NBC];
 #pragma unroll
-            for (int bi = 0; bi < NB; ++bi)
+                    for (int b = 0; b < NBC; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
+                    const double fb = (col < n && rj < n && col >= rj) ? f[NBC - 1] : 0.0;   // f[NBC - 1] is always block bj's own fragment
 #pragma unroll
-                for (int bj = bi; bj < NB; ++bj, ++t) {
-                    if (P.nu_out) {
+                    for (int b = 0; b < NBC; ++b) {
+                        if (b > bj) break;
+                        const double fa = (b == bj) ? fb : ((col < n) ? f[b] : 0.0);
+                        an[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, an[b], 0, 0, 0);
+                    }
+                }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
+                for (int b = 0; b < NBC; ++b) {
+                    if (b > bj) break;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        slab[(b * 4 + r) * WAVE] = old[b][r] + an[b][r];
+                        if (DBG && nu_doc) {
+                            const int i = b * 16 + fq + 4 * r, j = rj;
                             if (i < n && j < n) {
-                                P.nu_out[(size_t)doc * n * n + (size_t)i * n + j] = acc_nu[t][r];
-                                P.nu_out[(size_t)doc * n * n + (size_t)j * n + i] = acc_nu[t][r];
+                                nu_doc[(size_t)i * n + j] = an[b][r];
+                                nu_doc[(size_t)j * n + i] = an[b][r];
                             }
                         }
                     }
-                    acc_nu[t] += nud[t];
                 }
+            }
         }
-        if (P.prof && lane == 0) {
+        if (DBG && P.prof && lane == 0 && (P.debug_flags & 32)) for (int q2 = 0; q2 < 4; ++q2) P.prof[doc * 40 + 28 + q2] = tcc[q2];
+        if (DBG && P.prof && lane == 0) {
             tp[7] = (long long)__builtin_readcyclecounter();
-            for (int q = 0; q < 7; ++q) P.prof[doc * 40 + 32 + q] = tp[q + 1] - tp[q];
+            for (int q2 = 0; q2 < 7; ++q2) P.prof[doc * 40 + 32 + q2] = tp[q2 + 1] - tp[q2];
         }
     }
-
-    // ---- one flush of the workgroup's nu sum into its replica of sigma_ss
-    {
-        int t = 0;
-#pragma unroll
-        for (int bi = 0; bi < NB; ++bi)
-#pragma unroll
-            for (int bj = bi; bj < NB; ++bj, ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = bi * 16 + fq + 4 * r, j = bj * 16 + fr;
-                    if (i < n && j < n) {
-                        unsafeAtomicAdd(sig_acc + (size_t)i * n + j, acc_nu[t][r]);
-                        if (bi != bj) unsafeAtomicAdd(sig_acc + (size_t)j * n + i, acc_nu[t][r]);
-                    }
-                }
-        if (REM && isn) {
-            unsafeAtomicAdd(sig_acc + (size_t)lane * n + R0, nu_rem);
-            if (lane != R0) unsafeAtomicAdd(sig_acc + (size_t)R0 * n + lane, nu_rem);
-        }
-    }
-}
-
-// out = sum over the replicated / per-block partial copies, in a fixed order: 64 slots per block, the copies
-// split over four 64-thread groups, four independent partial sums per thread, then a fixed combine
-__global__ __launch_bounds__(256) void reduce_sigma_kernel(const double *part, int nblocks, int nn, double *out) {
-    __shared__ double sh[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + tx;
-    const int per = (nblocks + 3) >> 2;
-    const int b0 = ty * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    if (q < nn) {
-        int b = b0;
-        for (; b + 3 < b1; b += 4) {
-            const double a = part[(size_t)b * nn + q], c = part[(size_t)(b + 1) * nn + q];
-            const double d = part[(size_t)(b + 2) * nn + q], e = part[(size_t)(b + 3) * nn + q];
-            t0 += a; t1 += c; t2 += d; t3 += e;
-        }
-        for (; b < b1; ++b) t0 += part[(size_t)b * nn + q];
-    }
-    sh[ty][tx] = (t0 + t1) + (t2 + t3);
-    __syncthreads();
-    if (ty == 0 && q < nn) out[q] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
-}
-
-// bound = np.sum(calculated_bounds) (stm.py:592): one block, fixed tree => deterministic
-__global__ __launch_bounds__(1024) void reduce_bound_kernel(const double *bound, int64_t N, double *out) {
-    __shared__ double sh[1024];
-    double t = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += 1024) t += bound[i];
-    sh[threadIdx.x] = t;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 }  // namespace stm

@@ -9,7 +9,7 @@
 // inverse and nu = X^T X as in stm_post.h.  BASELINE config 4 (K = 100) runs here; see DESIGN.md 4.2b.
 #pragma once
 #include <type_traits>
-#include "stm_post.h"
+#include "stm_post_common.h"
 
 namespace stm {
 
@@ -716,14 +716,6 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         }
         __syncthreads();
     }
-}
-
-// sigma_ss[i][j] = sigma_ss[j][i] for the 16 x 16 blocks below the block diagonal (post_big_kernel adds nu's upper block triangle only)
-__global__ void mirror_blocks_kernel(double *a, int n) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n * n) return;
-    const int i = q / n, j = q % n;
-    if ((i >> 4) > (j >> 4)) a[q] = a[(size_t)j * n + i];
 }
 
 }  // namespace stm
