@@ -114,9 +114,10 @@ struct stm_handle {
     int32_t *d_indices = nullptr, *d_aspect = nullptr, *d_order = nullptr;
     double *d_counts = nullptr;
     // the corpus in word-major order (stm_betass.h): entries sorted by (level, word), ascending document within a row
-    int32_t *d_wm_doc = nullptr, *d_wm_pos = nullptr, *d_seg_row = nullptr, *d_seg_lo = nullptr, *d_seg_hi = nullptr;
-    uint8_t *d_seg_multi = nullptr;
-    int64_t nseg = 0;
+    int32_t *d_wm_doc = nullptr, *d_wm_pos = nullptr, *d_cptr = nullptr;
+    double *d_bss_part = nullptr;   // [G][A * V][K] partial sums of the word-major pass
+    int G = 1;                      // document groups of the word-major pass
+    std::vector<int32_t> h_indices, h_aspect;   // kept for the word-major build (stm_set_topics fixes the chunk size)
     double *d_rw = nullptr;     // [nnz] r_dw written by the post kernel
     size_t sigma_part_len = 0;
     // model
@@ -279,6 +280,47 @@ static int plan_solver(stm_handle *h) {
     return STM_OK;
 }
 
+// The corpus in word-major order for stm_betass.h: entries sorted by (level * V + word, document group), documents ascending.
+static int build_word_major(stm_handle *h) {
+    const int64_t N = h->N, nnz = h->nnz;
+    const size_t R = (size_t)h->A * (size_t)h->V;
+    const int64_t gdocs = std::max<int64_t>(1, (int64_t)env_int("STM_BETASS_GROUP_KB", stm::BETASS_GROUP_BYTES >> 10) * 1024 / ((int64_t)h->K * 8));
+    int64_t G = std::max<int64_t>(1, (N + gdocs - 1) / gdocs);
+    G = std::min<int64_t>(G, 64);
+    G = std::min<int64_t>(G, std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)std::max<size_t>(R * (size_t)h->K, 1)));   // <= 2 GB of partial sums
+    const int64_t gd = (N + G - 1) / G;   // documents per group
+    h->G = (int)G;
+    const int64_t *indptr = h->h_indptr.data();
+    const int32_t *indices = h->h_indices.data();
+    const bool asp = !h->h_aspect.empty();
+    std::vector<int32_t> cptr(R * (size_t)G + 1, 0);
+    for (int64_t d = 0; d < N; ++d) {
+        const size_t base = (asp ? (size_t)h->h_aspect[(size_t)d] : 0) * (size_t)h->V, g = (size_t)(d / gd);
+        for (int64_t q = indptr[d]; q < indptr[d + 1]; ++q) ++cptr[(base + (size_t)indices[q]) * (size_t)G + g + 1];
+    }
+    for (size_t r = 0; r + 1 < cptr.size(); ++r) cptr[r + 1] += cptr[r];
+    std::vector<int32_t> wm_doc((size_t)nnz), wm_slot((size_t)nnz), fill(cptr.begin(), cptr.end() - 1);
+    for (int64_t d = 0; d < N; ++d) {
+        const size_t base = (asp ? (size_t)h->h_aspect[(size_t)d] : 0) * (size_t)h->V, g = (size_t)(d / gd);
+        for (int64_t q = indptr[d]; q < indptr[d + 1]; ++q) {
+            const int32_t slot = fill[(base + (size_t)indices[q]) * (size_t)G + g]++;
+            wm_doc[(size_t)slot] = (int32_t)d;
+            wm_slot[(size_t)q] = slot;     // CSR position -> word-major slot (the post kernel scatters r there)
+        }
+    }
+    if (int rc = dalloc(&h->d_wm_doc, (size_t)nnz)) return rc;
+    if (int rc = dalloc(&h->d_wm_pos, (size_t)nnz)) return rc;
+    if (int rc = dalloc(&h->d_cptr, cptr.size())) return rc;
+    if (int rc = dalloc(&h->d_bss_part, (size_t)G * R * (size_t)h->K)) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_cptr, cptr.data(), sizeof(int32_t) * cptr.size(), hipMemcpyHostToDevice, h->stream));
+    if (nnz) {
+        HIP_TRY(hipMemcpyAsync(h->d_wm_doc, wm_doc.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_wm_pos, wm_slot.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the host vectors go out of scope
+    return STM_OK;
+}
+
 extern "C" {
 
 const char *stm_last_error(void) { return g_err.c_str(); }
@@ -324,7 +366,7 @@ void stm_destroy(stm_handle *h) {
     stm_mstep_comm_destroy(h->comm);
     stm_spectral_destroy(h->spectral);
     dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
-    dfree(h->d_wm_doc); dfree(h->d_wm_pos); dfree(h->d_seg_row); dfree(h->d_seg_lo); dfree(h->d_seg_hi); dfree(h->d_seg_multi); dfree(h->d_rw);
+    dfree(h->d_wm_doc); dfree(h->d_wm_pos); dfree(h->d_rw); dfree(h->d_cptr); dfree(h->d_bss_part);
     dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_colsum); dfree(h->d_eta); dfree(h->d_mu);
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
@@ -395,52 +437,13 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     if (N) HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
     h->h_len_sorted.resize((size_t)N);
     for (int64_t i = 0; i < N; ++i) h->h_len_sorted[(size_t)i] = (int32_t)(indptr[order[i] + 1] - indptr[order[i]]);
-    // word-major order (stm_betass.h): a counting sort of the CSR positions by (level, word); documents ascend within a row
+    // word-major order (stm_betass.h): a counting sort of the CSR positions by (level, word, document chunk); documents
+    // ascend within a row.  The chunk size is fixed when K is known (stm_set_topics); until then the entries are kept
+    // on the host.
     if (nnz >= (int64_t)1 << 31) return fail(STM_ERR_INVALID, "stm_set_corpus: nnz must be < 2^31 per GPU shard");
-    {
-        const size_t R = (size_t)A * (size_t)V;
-        std::vector<int32_t> cnt(R + 1, 0);
-        for (int64_t d = 0; d < N; ++d) {
-            const size_t base = (aspect && A > 1 ? (size_t)aspect[d] : 0) * (size_t)V;
-            for (int64_t q = indptr[d]; q < indptr[d + 1]; ++q) ++cnt[base + (size_t)indices[q] + 1];
-        }
-        for (size_t r = 0; r < R; ++r) cnt[r + 1] += cnt[r];
-        std::vector<int32_t> wm_doc((size_t)nnz), wm_pos((size_t)nnz), fill(cnt.begin(), cnt.end() - 1);
-        for (int64_t d = 0; d < N; ++d) {
-            const size_t base = (aspect && A > 1 ? (size_t)aspect[d] : 0) * (size_t)V;
-            for (int64_t q = indptr[d]; q < indptr[d + 1]; ++q) {
-                const int32_t slot = fill[base + (size_t)indices[q]]++;
-                wm_doc[(size_t)slot] = (int32_t)d;
-                wm_pos[(size_t)slot] = (int32_t)q;
-            }
-        }
-        std::vector<int32_t> seg_row, seg_lo, seg_hi;
-        std::vector<uint8_t> seg_multi;
-        for (size_t r = 0; r < R; ++r) {
-            const int32_t lo = cnt[r], hi = cnt[r + 1];
-            for (int32_t b = lo; b < hi; b += stm::BETASS_SEG) {
-                seg_row.push_back((int32_t)r); seg_lo.push_back(b); seg_hi.push_back(std::min(hi, b + stm::BETASS_SEG));
-                seg_multi.push_back(hi - lo > stm::BETASS_SEG ? 1 : 0);
-            }
-        }
-        h->nseg = (int64_t)seg_row.size();
-        if (int rc = dalloc(&h->d_wm_doc, (size_t)nnz)) return rc;
-        if (int rc = dalloc(&h->d_wm_pos, (size_t)nnz)) return rc;
-        if (int rc = dalloc(&h->d_rw, (size_t)nnz)) return rc;
-        if (int rc = dalloc(&h->d_seg_row, seg_row.size())) return rc;
-        if (int rc = dalloc(&h->d_seg_lo, seg_row.size())) return rc;
-        if (int rc = dalloc(&h->d_seg_hi, seg_row.size())) return rc;
-        if (int rc = dalloc(&h->d_seg_multi, seg_row.size())) return rc;
-        if (nnz) {
-            HIP_TRY(hipMemcpyAsync(h->d_wm_doc, wm_doc.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->d_wm_pos, wm_pos.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->d_seg_row, seg_row.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->d_seg_lo, seg_lo.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->d_seg_hi, seg_hi.data(), sizeof(int32_t) * seg_row.size(), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(h->d_seg_multi, seg_multi.data(), seg_row.size(), hipMemcpyHostToDevice, h->stream));
-        }
-        HIP_TRY(hipStreamSynchronize(h->stream));   // the host vectors go out of scope
-    }
+    h->h_indices.assign(indices, indices + nnz);
+    if (aspect && A > 1) h->h_aspect.assign(aspect, aspect + N); else h->h_aspect.clear();
+    if (int rc = dalloc(&h->d_rw, (size_t)nnz)) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->K = 0;
     return STM_OK;
@@ -481,6 +484,7 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = dalloc(&h->d_pd, N)) return rc;
     if (int rc = dalloc(&h->d_counters, 8)) return rc;
     if (int rc = dalloc(&h->d_err, 1)) return rc;
+    if (K <= stm::PT) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (the K > 64 kernels add phi atomically)
     // one block (one wave) per document.  The solver keeps beta_d on chip (64 words in registers,
     // the rest in LDS); launches are cut so every launch has one LDS size / occupancy class.
     if (int rc = plan_solver(h)) return rc;
@@ -757,14 +761,20 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
         HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
         pp.sigma_part = h->d_sigma_part; pp.nrep = nrep;
-        pp.rw = h->d_rw;
+        pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
         hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
-        if (!big && !v1 && h->nseg > 0) {   // beta_ss from the r_dw the post kernel left behind (stm_betass.h)
+        if (!big && !v1 && h->nnz > 0) {   // beta_ss from the r_dw the post kernel left behind (stm_betass.h)
             stm::BetaSsParams bp{};
-            bp.K = K; bp.nseg = h->nseg; bp.seg_row = h->d_seg_row; bp.seg_lo = h->d_seg_lo; bp.seg_hi = h->d_seg_hi; bp.seg_multi = h->d_seg_multi;
-            bp.wm_doc = h->d_wm_doc; bp.wm_pos = h->d_wm_pos; bp.rw = h->d_rw; bp.theta = h->d_theta; bp.betaT = h->d_betaT; bp.beta_ssT = h->d_beta_ssT;
-            hipLaunchKernelGGL(stm::beta_ss_kernel, dim3((unsigned)((h->nseg + 3) / 4)), dim3(256), 0, h->stream, bp);
+            bp.K = K; bp.G = h->G; bp.R = (int64_t)h->A * h->V; bp.cptr = h->d_cptr; bp.wm_doc = h->d_wm_doc; bp.rw = h->d_rw;
+            bp.theta = h->d_theta; bp.betaT = h->d_betaT; bp.part = h->d_bss_part; bp.beta_ssT = h->d_beta_ssT;
+            const int rows = env_int("STM_BETASS_ROWS", stm::BETASS_ROWS_DEFAULT), depth = env_int("STM_BETASS_DEPTH", 8);
+            const int64_t wpg = (bp.R + rows - 1) / rows, bpg = (wpg + 3) / 4;
+            auto fn = rows == 4 ? (depth == 16 ? stm::beta_ss_part_kernel<16, 4> : stm::beta_ss_part_kernel<8, 4>)
+                    : rows == 16 ? (depth == 16 ? stm::beta_ss_part_kernel<16, 16> : stm::beta_ss_part_kernel<8, 16>)
+                    : (depth == 16 ? stm::beta_ss_part_kernel<16, 8> : stm::beta_ss_part_kernel<8, 8>);
+            hipLaunchKernelGGL(fn, dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+            hipLaunchKernelGGL(stm::beta_ss_reduce_kernel, dim3((unsigned)((bp.R * K + 255) / 256)), dim3(256), 0, h->stream, bp);
             HIP_TRY(hipGetLastError());
         }
     }

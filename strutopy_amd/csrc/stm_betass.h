@@ -6,71 +6,102 @@
 // an XCD cannot keep (beta and beta_ss are 4 MB each) -- a floor of ~5 ms whatever the kernel around them does.
 // phi factorises:   phi[k, (d, w)] = beta[v][k] * exp(eta~_d)[k] * c_dw / S_dw = beta[v][k] * theta_d[k] * r_dw,
 //                   r_dw = sum_k exp(eta~_d)[k] * c_dw / S_dw   (S_dw = the column sum the post kernel has anyway),
-// so the post kernel only stores the scalar r_dw per (document, word) and this kernel computes, for every (level, word) row,
+// so the post kernel only stores the scalar r_dw per (document, word) -- scattered to the entry's slot in word-major order --
+// and this pass computes, for every (level, word) row,
 //   beta_ss[a][v][:] = beta[a][v][:] * sum_{(d, w): word v, level a} theta_d[:] * r_dw
-// as one gather of theta rows per entry -- a sparse (words x documents) times dense (documents x K) product over the
-// corpus in word-major order (built once per corpus by stm_set_corpus: a counting sort).  No atomics, and the entries of a
-// row are added in ascending document order: beta_ss is run-to-run identical.  Rows longer than SEG entries (the
-// most frequent words of a real vocabulary) are cut into segments whose partial sums are added atomically.
+// as one gather of theta rows per entry: a sparse (words x documents) times dense (documents x K) product over the corpus in
+// word-major order (built once per corpus and K: a counting sort).  No atomics, every sum in a fixed order: beta_ss is
+// run-to-run identical.
+// The gather is what costs: 15 M rows of 8K bytes out of a theta that is ten times an XCD's L2.  So the documents are cut
+// into G groups small enough for L2 (BETASS_GROUP_BYTES of theta), the grid is ordered group-major -- at any time the
+// whole chip gathers from one or two groups -- and a wave writes the partial sum of its (row, group) cells; a second kernel
+// adds the G partials of a row in order and multiplies by beta.
 #pragma once
 #include "stm_wave.h"
 
 namespace stm {
 
 struct BetaSsParams {
-    int K;
-    int64_t nseg;
-    const int32_t *seg_row;   // (level * V + word) of the segment
-    const int32_t *seg_lo;    // entries [seg_lo, seg_hi) of the word-major arrays
-    const int32_t *seg_hi;
-    const uint8_t *seg_multi; // 1: the row has more than one segment (atomic add instead of a store)
+    int K, G;                 // topics; document groups
+    int64_t R;                // rows = levels * V
+    const int32_t *cptr;      // [R * G + 1] first entry of (row, group) in the word-major arrays
     const int32_t *wm_doc;    // word-major: document of the entry
-    const int32_t *wm_pos;    // word-major: position of the entry in the document-major (CSR) arrays
-    const double *rw;         // [nnz] r_dw, document-major (post kernel)
+    const double *rw;         // [nnz] r_dw, WORD-major (the post kernel scatters it there through its copy of the slot map)
     const double *theta;      // [N][K]
     const double *betaT;      // [A][V][K]
-    double *beta_ssT;         // [A][V][K] (pre-zeroed)
+    double *part;             // [G][R][K] partial sums
+    double *beta_ssT;         // [A][V][K]
 };
 
-constexpr int BETASS_SEG = 4096;
+constexpr int BETASS_GROUP_BYTES = 1 << 20;   // theta bytes per document group
+constexpr int BETASS_ROWS_DEFAULT = 4;        // rows per wave
 
-// one wave per segment, lane = topic; 64 entries per batch: their (document, r) pairs are fetched lane-parallel and handed
-// out with v_readlane, eight theta rows in flight
-__global__ __launch_bounds__(256) void beta_ss_kernel(BetaSsParams P) {
+// One wave per (BETASS_ROWS rows, group), lane = topic; blockIdx is group-major.  A cell's (document, r) pairs are fetched
+// lane-parallel -- the next cell's while the current one is consumed -- and handed out with v_readlane, DEPTH theta rows in flight.
+template <int DEPTH, int BETASS_ROWS>
+__global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
     const int lane = threadIdx.x & 63;
-    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (seg >= P.nseg) return;
-    const int K = P.K;
-    const int row = P.seg_row[seg], lo = P.seg_lo[seg], hi = P.seg_hi[seg];
+    const int K = P.K, G = P.G;
+    const int64_t R = P.R, wpg = (R + BETASS_ROWS - 1) / BETASS_ROWS;     // waves per group
+    const int64_t bpg = (wpg + 3) / 4;                                      // blocks per group
+    const int g = (int)(blockIdx.x / bpg);
+    const int64_t wv = (blockIdx.x % bpg) * 4 + (threadIdx.x >> 6);
+    if (wv >= wpg) return;
+    const int64_t r0 = wv * BETASS_ROWS, r1 = r0 + BETASS_ROWS < R ? r0 + BETASS_ROWS : R;
     const int kl = lane < K ? lane : 0;
+    const double *th0 = P.theta + kl;
+    // lane q <= rows: the cell boundaries cp[(r0 + q) * G + g] and, in the next lane block, their ends
+    const int nr = (int)(r1 - r0);
+    const int lo_l = lane < nr ? P.cptr[(r0 + lane) * G + g] : 0, hi_l = lane < nr ? P.cptr[(r0 + lane) * G + g + 1] : 0;
+    auto fetch = [&](int e0, int e1, int &d, double &r) __attribute__((always_inline)) {   // entries [e0, min(e1, e0 + 64))
+        const bool in = e0 + lane < e1;
+        const int el = in ? e0 + lane : 0;                 // lanes beyond the batch read entry 0 and carry r = 0
+        d = P.wm_doc[el];
+        const double rv = P.rw[el];
+        r = in ? rv : 0.0;
+    };
+    int q = 0;
+    int e0 = __builtin_amdgcn_readlane(lo_l, 0), e1 = __builtin_amdgcn_readlane(hi_l, 0);
+    int dl, dn = 0;
+    double rl, rn = 0.0;
+    fetch(e0, e1, dl, rl);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int e0 = lo; e0 < hi; e0 += WAVE) {
-        const int cnt = hi - e0 < WAVE ? hi - e0 : WAVE;
-        const int el = e0 + (lane < cnt ? lane : 0);
-        const int dl = P.wm_doc[el];
-        const double rl = lane < cnt ? P.rw[P.wm_pos[el]] : 0.0;
-        int u = 0;
-        for (; u + 7 < cnt; u += 8) {
-            double th[8], r[8];
+    while (q < nr) {
+        const int cnt = e1 - e0 < WAVE ? e1 - e0 : WAVE;
+        // the batch after this one: the rest of the cell, or the next row's cell
+        int nq = q, n0 = e0 + WAVE, n1 = e1;
+        if (n0 >= e1) {
+            nq = q + 1;
+            if (nq < nr) { n0 = __builtin_amdgcn_readlane(lo_l, nq); n1 = __builtin_amdgcn_readlane(hi_l, nq); }
+        }
+        if (nq < nr) fetch(n0, n1, dn, rn);
+        for (int u = 0; u < cnt; u += DEPTH) {   // DEPTH loads all the same: the entries beyond cnt carry r = 0
+            double th[DEPTH], r[DEPTH];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int d = __builtin_amdgcn_readlane(dl, u + q);
-                th[q] = P.theta[(size_t)d * K + kl];
-                r[q] = lane_bcast(rl, u + q);
+            for (int t = 0; t < DEPTH; ++t) {
+                const int ut = (u + t) & (WAVE - 1);
+                const int d = __builtin_amdgcn_readlane(dl, ut);
+                th[t] = th0[(size_t)d * K];
+                r[t] = lane_bcast(rl, ut);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q & 3] = fma(th[q], r[q], acc[q & 3]);
+            for (int t = 0; t < DEPTH; ++t) acc[t & 3] = fma(th[t], r[t], acc[t & 3]);
         }
-        for (; u < cnt; ++u) {
-            const int d = __builtin_amdgcn_readlane(dl, u);
-            acc[u & 3] = fma(P.theta[(size_t)d * K + kl], lane_bcast(rl, u), acc[u & 3]);
+        if (nq != q) {   // the cell is complete
+            if (lane < K) P.part[((size_t)g * R + (size_t)(r0 + q)) * K + lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
         }
+        q = nq; e0 = n0; e1 = n1; dl = dn; rl = rn;
     }
-    if (lane < K) {
-        const double v = P.betaT[(size_t)row * K + lane] * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
-        if (P.seg_multi[seg]) unsafeAtomicAdd(P.beta_ssT + (size_t)row * K + lane, v);
-        else P.beta_ssT[(size_t)row * K + lane] = v;
-    }
+}
+
+// beta_ss[row][k] = beta[row][k] * sum_g part[g][row][k], groups in ascending order
+__global__ __launch_bounds__(256) void beta_ss_reduce_kernel(BetaSsParams P) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, RK = P.R * P.K;
+    if (q >= RK) return;
+    double t = 0.0;
+    for (int g = 0; g < P.G; ++g) t += P.part[(size_t)g * RK + q];
+    P.beta_ssT[q] = P.betaT[q] * t;
 }
 
 }  // namespace stm

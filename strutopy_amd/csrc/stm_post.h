@@ -63,7 +63,7 @@ __host__ __device__ inline PostLds post_lds_map(int K, int NB) {
     const int tile_part = L.eth + 8 * L.qp;
     L.mdump = tri_row(n) + 16;
     L.vec = L.mdump + 2;
-    const int mat_part = L.vec + 64;
+    const int mat_part = L.vec + 64 + 64;   // + the Cholesky panel's column broadcast
     L.total = ((tile_part > mat_part ? tile_part : mat_part) + 1) & ~1;
     return L;
 }
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
     double *M = post_lds;            // row-packed lower triangle (after the word loop)
     double *wpar = post_lds + LM.wpar, *sex = post_lds + LM.sex, *eth = post_lds + LM.eth;
     double *vec = post_lds + LM.vec;
+    double *cb = vec + 64;           // the Cholesky panel's column broadcast
     double *sth = vec;               // word loop .. PD ladder: stable_softmax(eta~) (stm.py:998,1083)
     double *sdv = vec;               // bound: eta - mu broadcast (dense siginv only)
     double *srd = vec;               // inverse: 1 / diag(L)
@@ -138,10 +139,11 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
 
         // word ids (lane w < 16: word t0 + w) and counts (lane 4 w + q: word t0 + w) of a tile; lanes beyond the document
         // repeat its last word (a valid row for the fetch)
-        auto load_ids = [&](int t0, int &idx, double &c) __attribute__((always_inline)) {
+        auto load_ids = [&](int t0, int &idx, double &c, int &slot) __attribute__((always_inline)) {
             const int wi = t0 + lane, wc = t0 + (lane >> 2), last = Nd - 1;
             idx = P.indices[p0 + (wi < last ? wi : last)];
             c = P.counts[p0 + (wc < last ? wc : last)];   // masked where it is used: a select here would wait for the load at once
+            slot = P.wm_slot[p0 + (wc < last ? wc : last)];   // where this word's r goes (stm_betass.h)
         };
         // the 16 rows of a tile, betaT -> LDS: chunk c = 64 q + lane (16 bytes) is chunk c mod PC of word c / PC.  Chunks
         // beyond the topics of a row (K below this instantiation's maximum) repeat its last one: finite, and the sums
@@ -182,10 +184,10 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             }
         };
 
-        int idx0, idx1;
+        int idx0, idx1, sl0, sl1;
         double c0, c1;
-        load_ids(0, idx0, c0);
-        load_ids(TW, idx1, c1);
+        load_ids(0, idx0, c0, sl0);
+        load_ids(TW, idx1, c1, sl1);
 
         // ---- eta~, theta (unshifted softmax, stm.py:547-549), stable softmax, exp(eta~)
         const double eta_i = isn ? P.eta[doc * n + lane] : 0.0;  // lane K-1 holds the appended 0
@@ -227,9 +229,9 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             STM_POST_SYNC();
             double *T = post_lds + buf * TILE;
             if (t0 + TW < Nd) tile_fetch(idx1, buf ^ 1);   // the other buffer's readers finished a tile ago
-            int idx2;
+            int idx2, sl2;
             double c2;
-            load_ids(t0 + 2 * TW, idx2, c2);              // plain loads: the compiler waits for them where they are first read
+            load_ids(t0 + 2 * TW, idx2, c2, sl2);         // plain loads: the compiler waits for them where they are first read
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[0] += cy - cy0; cy0 = cy; }
             // -- 1. per-word sums, lane = (word lane >> 2, quarter lane & 3 of the row; zeros of sex / eth from K on)
             {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 if (own) *reinterpret_cast<double2 *>(wpar + 2 * w) = make_double2(wq, sq);
                 // phi = beta * theta * r (stm_betass.h): r = exp-sum * c / S, in update_z's association (sqrt(c) / S) * sqrt(c).
                 // assert np.all(phi >= 0) (stm.py:1117) fails exactly when a column sum is 0 (0 * inf), infinite or NaN.
-                if (valid && own) P.rw[p0 + t0 + w] = (wq * sq) * sumex;
+                if (valid && own) P.rw[sl0] = (wq * sq) * sumex;
                 sbad |= valid && !(Sw > 0.0 && Sw < INFINITY);
             }
             STM_POST_SYNC();
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             STM_POST_SYNC();
             wait_lds();         // every read of this buffer has returned before the tile after next is fetched into it
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[3] += cy - cy0; }
-            idx0 = idx1; c0 = c1; idx1 = idx2; c1 = c2;
+            idx0 = idx1; c0 = c1; sl0 = sl1; idx1 = idx2; c1 = c2; sl1 = sl2;
         }
         STM_POST_SYNC();
         sth[lane] = isk ? ths : 0.0;   // inside region 0, behind the matrix: the tiles are done
@@ -420,26 +422,44 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 double w[16];
 #pragma unroll
                 for (int c2 = 0; c2 < 8; ++c2) { const double2 t = wr[c2]; w[2 * c2] = t.x; w[2 * c2 + 1] = t.y; }
-                bool bad = false;
+                // Column J's finished entries reach the other lanes through a 64-entry LDS column (one store, then broadcast
+                // reads two at a time -- no v_readlane pair per update), one column behind: the update with column J-1 is
+                // applied while column J's pivot chain runs.  That chain does not wait for it: lane J owns row J, so its
+                // fully updated diagonal entry is w[j] - L[J][J-1]^2 from its own registers (the very fma the update
+                // below performs for that lane).
+                bool badl = false;
                 if (DBG && P.prof) { pin(w[0]); pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[1] += c1 - cq; cq = c1; }
+                double *cbw = cb + lane;
+                const double *cbr = cb + J0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     if (J0 + j < n) {   // uniform
                         const int J = J0 + j;
-                        const double d = lane_bcast(w[j], J);
-                        const double dA = lane_bcast(diagA, J);
-                        bad |= !(d > PIVOT_TOL * dA);           // see PIVOT_TOL
+                        const double tmp = j > 0 ? fma(-w[j > 0 ? j - 1 : 0], w[j > 0 ? j - 1 : 0], w[j]) : w[0];
+                        const double d = lane_bcast(tmp, J);
+                        badl |= (lane == J) && !(tmp > PIVOT_TOL * diagA);   // see PIVOT_TOL
                         double ljj, rjj;                        // LAPACK dpotf2 scales the column by the reciprocal as well
                         sqrt_and_rsqrt(d, ljj, rjj);
                         if (lane == J) Ldiag = ljj;
-                        w[j] *= rjj;
+                        if (j > 0) {   // the update with column J - 1 (stored at the end of the previous step), four broadcasts at a time
 #pragma unroll
-                        for (int c = j + 1; c < 16; ++c) {
-                            const double x = lane_bcast(w[j], (J0 + c) & 63);   // L[J0 + c][J]
-                            w[c] = fma(-w[j], x, w[c]);
+                            for (int c0 = j; c0 < 16; c0 += 4) {
+                                double xs[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) if (c0 + u < 16) xs[u] = cbr[c0 + u];   // L[J0 + c][J - 1]
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) if (c0 + u < 16) w[c0 + u] = fma(-w[j > 0 ? j - 1 : 0], xs[u], w[c0 + u]);
+                            }
+                        }
+                        w[j] *= rjj;
+                        if (j < 15) {
+                            STM_POST_SYNC();
+                            *cbw = w[j];
+                            STM_POST_SYNC();
                         }
                     }
                 }
+                const bool bad = wave_any(badl);
                 if (DBG && P.prof) { pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[2] += c1 - cq; cq = c1; }
                 if (bad) { ok = false; break; }
                 // pairs (c, c + 1) with the first cell strictly below the diagonal; the second one is then at most the

@@ -39,7 +39,8 @@ struct PostParams {
     double *phi_out;       // [K][Nd(phi_doc)]
     int MLD;               // leading dimension of the LDS matrix (odd, >= n)
     long long *prof;       // optional [N][40] (shared with the solver's): [32..39] post-kernel phase cycles
-    double *rw;            // post_kernel (K <= 64): [nnz] r_dw of stm_betass.h, document-major
+    double *rw;            // post_kernel (K <= 64): [nnz] r_dw of stm_betass.h, word-major ...
+    const int32_t *wm_slot; // ... at wm_slot[CSR position]
 };
 
 // A Cholesky pivot that is only the rounding left over from cancelling the diagonal entry counts as failed (as in the
