@@ -225,9 +225,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     __shared__ double xch_xt[NW == 2 ? WAVE : 1];   // trial point
     __shared__ double xch_gv[NW == 2 ? WAVE : 1];   // df at the trial point / partial g0
     __shared__ double xch_res[8];                   // [0] data-term share, [1] quadratic form, [2] m, [4..5] word-count shares, [6..7] rho, cc of a BFGS update
-    __shared__ int xch_cmd[4];                      // [0] request bits (1 f, 2 g, 4 exit, 8 BFGS update (16: from the identity)), [1..2] bad-beta flags
+    __shared__ int xch_cmd[4];
+    __shared__ double ss[64];                       // the scalar state of the line searches (struct ud; wave 0's, Ndoc both waves')
+    enum : int { U_old_fval, U_old_old_fval, U_gnorm, U_phi0, U_old_phi0, U_derphi0, U_Lb, U_Lv, U_prange, U_stx, U_fx, U_gx, U_sty, U_fy, U_gy, U_stmin, U_stmax, U_width, U_width1, U_finit, U_ginit, U_gtest, U_w1_a1, U_w1_f1, U_alpha0, U_alpha1, U_phi_a0, U_phi_a1, U_derphi_a0, U_a_lo, U_a_hi, U_phi_lo, U_phi_hi, U_derphi_lo, U_phi_rec, U_a_rec, U_a_j, U_acc_alpha, U_acc_f, U_alpha, U_fval, U_dval, U_cache_f, U_Ndoc, U_sig_lmax, U_COUNT };
+    static_assert(U_COUNT <= 64, "scalar state");                      // [0] request bits (1 f, 2 g, 4 exit, 8 BFGS update (16: from the identity)), [1..2] bad-beta flags
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = NW == 2 ? (int)(threadIdx.x >> 6) : 0;
+    if (threadIdx.x < 64) ss[threadIdx.x] = 0.0;   // (read only after the first workgroup barrier)
     const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
     double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
     // DIRECT: dyn_lds = tile[TWS][KP] | crow[ld] | wrow[ld] | sidx[ld] (int32)
@@ -410,7 +414,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
             return;
         }
-        const ud Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
+        STM_UD(ss, Ndoc);
+        Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
         if (COOP && NdL > 0) {
             // lane = word again for the column sums of the slab rows (same order of additions as the per-lane gather loop);
             // only this wave reads crow / wrow before the next hand-off
@@ -925,27 +930,28 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // ---- scipy _minimize_bfgs state (optimize/_optimize.py:1328-1502)
         const double gtol = 1e-5, c1 = 1e-4, c2 = 0.9, amax = 1e100, amin = 1e-100, xtol = 1e-14;
         const int maxiter = n * 200;
-        ud old_fval, old_old_fval, gnorm;
+        STM_UD(ss, old_fval); STM_UD(ss, old_old_fval); STM_UD(ss, gnorm);
         int k = 0, status = 0;
         bool H_ident = true;
         // line-search shared
-        ud phi0, old_phi0, derphi0, Lb, Lv, prange;
-        const ud sig_lmax = P.sig_bound;
+        STM_UD(ss, phi0); STM_UD(ss, old_phi0); STM_UD(ss, derphi0); STM_UD(ss, Lb); STM_UD(ss, Lv); STM_UD(ss, prange);
+        STM_UD(ss, sig_lmax);
+        sig_lmax = P.sig_bound;
         // DCSRCH state (optimize/_dcsrch.py)
-        ud stx, fx, gx, sty, fy, gy, stmin, stmax, width, width1, finit, ginit, gtest;
+        STM_UD(ss, stx); STM_UD(ss, fx); STM_UD(ss, gx); STM_UD(ss, sty); STM_UD(ss, fy); STM_UD(ss, gy); STM_UD(ss, stmin); STM_UD(ss, stmax); STM_UD(ss, width); STM_UD(ss, width1); STM_UD(ss, finit); STM_UD(ss, ginit); STM_UD(ss, gtest);
         int stage = 1, w1_calls = 0;
-        ud w1_a1, w1_f1;          // DCSRCH's first trial step and its function value (wolfe2 starts at the same step)
+        STM_UD(ss, w1_a1); STM_UD(ss, w1_f1);          // DCSRCH's first trial step and its function value (wolfe2 starts at the same step)
         bool w1_have = false;
         bool brackt = false;
         // wolfe2 / zoom state (optimize/_linesearch.py)
-        ud alpha0, alpha1, phi_a0, phi_a1, derphi_a0;
+        STM_UD(ss, alpha0); STM_UD(ss, alpha1); STM_UD(ss, phi_a0); STM_UD(ss, phi_a1); STM_UD(ss, derphi_a0);
         int w2_i = 0;
-        ud a_lo, a_hi, phi_lo, phi_hi, derphi_lo, phi_rec, a_rec, a_j;
+        STM_UD(ss, a_lo); STM_UD(ss, a_hi); STM_UD(ss, phi_lo); STM_UD(ss, phi_hi); STM_UD(ss, derphi_lo); STM_UD(ss, phi_rec); STM_UD(ss, a_rec); STM_UD(ss, a_j);
         int zi = 0;
-        ud acc_alpha, acc_f;
+        STM_UD(ss, acc_alpha); STM_UD(ss, acc_f);
         bool acc_have_g = false;
         // evaluation request / result + scipy ScalarFunction's last-x cache
-        ud alpha, fval, dval, cache_f;
+        STM_UD(ss, alpha); STM_UD(ss, fval); STM_UD(ss, dval); STM_UD(ss, cache_f);
         bool want_eval = true, need_f = true, need_g = true;
         bool have_x = false, f_ok = false, g_ok = false;
         int st = S_INIT_DONE;

@@ -2,8 +2,7 @@
 //
 // One wavefront (64 lanes) owns one document.  Vectors of length n = K-1 live one
 // component per lane (VPL components per lane when n > 64); scalars of the line search
-// are wave-uniform and are pinned to SGPRs with uni() so the solver's control flow
-// compiles to scalar branches.
+// are wave-uniform (struct ud: LDS slots), so the solver's control flow compiles to scalar branches.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,22 +19,19 @@ __device__ __forceinline__ double uni(double v) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// A wave-uniform double pinned to an SGPR pair on every assignment.  fp64 arithmetic is VALU-only,
-// so without the pin every line-search scalar would occupy a VGPR pair in all 64 lanes; as SGPRs
-// (spilled, when they must be, to single VGPR lanes) the ~40 solver scalars cost a few registers.
+// A wave-uniform double of the solver's scalar state machine, kept in an LDS slot: a state loads what it reads (one
+// broadcast ds_read_b64 each, in flight together), computes on VGPR copies and stores what it changes.  fp64 arithmetic is
+// VALU-only: pinned to SGPRs instead (rounds 1-2) the ~45 scalars overflowed the SGPR file and every use paid v_readlane /
+// v_mov / s_nop plumbing (solver 6.16 -> 5.59 ms over the driver's first twelve iterations); as plain VGPR values they
+// would cost 90 registers next to beta_d's 100.
 struct ud {
-    // held as two 32-bit integers: a loop-carried f64 is always given a VGPR pair by the
-    // compiler, a uniform i32 stays scalar
-    int lo, hi;
-    __device__ __forceinline__ ud() : lo(0), hi(0) {}
-    __device__ __forceinline__ ud(double x) { set(x); }
-    __device__ __forceinline__ ud &operator=(double x) { set(x); return *this; }
-    __device__ __forceinline__ operator double() const { return __hiloint2double(hi, lo); }
-    __device__ __forceinline__ void set(double x) {
-        lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
-        hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    }
+    double *p;
+    __device__ __forceinline__ explicit ud(double *slot) : p(slot) {}
+    __device__ __forceinline__ ud &operator=(double x) { *p = x; return *this; }
+    __device__ __forceinline__ ud &operator=(const ud &o) { *p = *o.p; return *this; }
+    __device__ __forceinline__ operator double() const { return *p; }
 };
+#define STM_UD(ss, n) ud n((ss) + U_##n)
 
 // Uniform read of kernel-lifetime-constant global data through the scalar cache (s_load): the compiler only does this on
 // its own when it can prove that nobody writes the buffer, which it cannot for plain pointers in a parameter struct.
@@ -58,22 +54,39 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
 // on uniform operands, so the result is wave-uniform (SGPR-resident) by construction.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
+    // a full permutation inside the rows (all rows and banks enabled): no lane keeps its old destination, so none is
+    // set up (with old = the source the compiler copies both halves first)
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// row_bcast:15 / row_bcast:31 into the rows of ROWS; the other rows receive FILL
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_bcast(double v, double fill) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, CTRL, ROWS, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, CTRL, ROWS, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141; // row_half_mirror
 constexpr int DPP_MIRROR = 0x140;      // row_mirror
+constexpr int DPP_BCAST15 = 0x142;     // row_bcast:15: lane 15 of the row before, to every lane of rows 1 and 3 (row_mask 0xa)
+constexpr int DPP_BCAST31 = 0x143;     // row_bcast:31: lane 31, to every lane of rows 2 and 3 (row_mask 0xc)
 
+// wave64 all-reduce: 4 butterfly steps leave every lane of a 16-lane row holding the row total r0..r3; two broadcast steps
+// then build (r3 + r2) + (r1 + r0) in row 3 -- bit for bit the (r0 + r1) + (r2 + r3) of four v_readlane and three adds,
+// at half the instructions -- and lane 63 hands it out, wave-uniform (SGPR-resident) by construction.
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_move<DPP_XOR1>(v);
     v += dpp_move<DPP_XOR2>(v);
     v += dpp_move<DPP_HALF_MIRROR>(v);
     v += dpp_move<DPP_MIRROR>(v);
-    return uni((lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48)));
+    v += dpp_bcast<DPP_BCAST15, 0xa>(v, 0.0);
+    v += dpp_bcast<DPP_BCAST31, 0xc>(v, 0.0);
+    return lane_bcast(v, 63);
 }
 // np.max semantics: NaN propagates
 __device__ __forceinline__ double nanmax(double a, double b) {
@@ -87,8 +100,10 @@ __device__ __forceinline__ double wave_nanmax(double v) {
     v = fmax(v, dpp_move<DPP_XOR2>(v));
     v = fmax(v, dpp_move<DPP_HALF_MIRROR>(v));
     v = fmax(v, dpp_move<DPP_MIRROR>(v));
-    const double m = fmax(fmax(lane_bcast(v, 0), lane_bcast(v, 16)), fmax(lane_bcast(v, 32), lane_bcast(v, 48)));
-    return uni(has_nan ? __builtin_nan("") : m);
+    v = fmax(v, dpp_bcast<DPP_BCAST15, 0xa>(v, v));
+    v = fmax(v, dpp_bcast<DPP_BCAST31, 0xc>(v, v));
+    const double m = lane_bcast(v, 63);
+    return has_nan ? __builtin_nan("") : m;
 }
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p) != 0; }
 // sqrt(d) and 1 / sqrt(d) together (d > 0): the coupled Goldschmidt iteration the compiler itself expands sqrt() into
