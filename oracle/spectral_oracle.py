@@ -15,9 +15,13 @@ Follows reference src/modules/stm.py:30-296 AS IMPORTED IN THIS IMAGE (scipy 1.1
   recover_l2    :229-296 per word the QP  min 1/2 x^T P x + q^T x  s.t. x <= 0  (P = M M^T, q = M y, M = anchor rows of
                          Q), weights = -x, i.e. the non-negative least-squares fit  min || M^T w - y ||, w >= 0
                          (no sum-to-one constraint, :244-246 is commented out); anchors get a one-hot row (:261-264).
-                         The reference calls qpsolvers.solve_qp(solver="quadprog"), absent from this image: the QP is
-                         strictly convex, so its minimiser does not depend on the solver; scipy.optimize.nnls solves it
-                         here (PARITY UNPINNED for this one step: no reference output can be generated offline).
+                         The reference calls qpsolvers.solve_qp(solver="quadprog") -- a third-party dependency that is
+                         absent from this image (pyproject.toml: qpsolvers[quadprog]; uv.lock pins quadprog 0.1.13).
+                         quadprog is R's solve.QP: the dual active-set method of Goldfarb & Idnani, "A numerically
+                         stable dual method for solving strictly convex quadratic programs", Mathematical Programming
+                         27 (1983) 1-33.  `solve_qp_goldfarb_idnani` below restates that published algorithm (steps
+                         0-2 of its section 3) and `recover_l2` runs it; tests/test_spectral.py also holds it against
+                         the non-negative least-squares form on both fixtures' inputs.
 
 Only tests/, __graft_entry__.smoke() and tools/ import this module.
 """
@@ -73,22 +77,121 @@ def fast_anchor(Q, K):
     return basis, Q_caller
 
 
-def recover_l2(Q, anchor, wprob):
-    """stm.py:229-296 with scipy.optimize.nnls in place of quadprog (see the module docstring)."""
+def solve_qp_goldfarb_idnani(P, q, G, h, max_iter=None, Pinv=None):
+    """min 1/2 x'Px + q'x  s.t.  G x <= h, P symmetric positive definite: the dual active-set method of Goldfarb & Idnani
+    (1983), the algorithm behind quadprog / R's solve.QP that the reference reaches through qpsolvers (stm.py:271-281).
+
+    In the paper's notation the constraints are n_j' x >= b_j (here n_j = -G[j], b_j = -h[j]); N holds the normals of the
+    active set A, u >= 0 its multipliers, and with N* = (N' P^-1 N)^-1 N' P^-1 and H = P^-1 (I - N N*):
+      step 0  x = -P^-1 q (the unconstrained minimum), A empty
+      step 1  pick a violated constraint p (quadprog: the largest violation relative to the length of its normal);
+              none -> x is optimal
+      step 2  z = H n_p (primal step direction), r = N* n_p (dual step direction);
+              t1 = min { u_k / r_k : r_k > 0 } (keeps u >= 0; k leaves A), t2 = -s_p / (z' n_p) (makes p active), t = min;
+              t infinite: infeasible.  z = 0: dual step only (u -= t r, u_p += t), drop k, repeat step 2.
+              Otherwise x += t z, u -= t r, u_p += t; full step (t = t2): p joins A, back to step 1; partial step:
+              drop k, repeat step 2.
+    Dense NumPy with the operators rebuilt from their definitions at every step (n <= 128 here); `Pinv`: P^-1 when the
+    caller solves many QPs with the same P (recover_l2: one per term)."""
+    P = np.asarray(P, dtype=np.float64)
+    q = np.asarray(q, dtype=np.float64).ravel()
+    Nall = -np.asarray(G, dtype=np.float64).T          # column j = n_j
+    b = -np.asarray(h, dtype=np.float64).ravel()
+    m = Nall.shape[1]
+    if Pinv is None:
+        L = np.linalg.cholesky(P)
+        Pinv = np.linalg.solve(L.T, np.linalg.solve(L, np.eye(len(q))))
+
+    def psolve(v):                                      # P^-1 v
+        return Pinv @ v
+
+    norms = np.sqrt(np.sum(Nall * Nall, axis=0))
+    x = -psolve(q)
+    A, u = [], np.zeros(0)
+    eps = np.finfo(float).eps
+    it, max_iter = 0, (max_iter or 50 * (m + len(q)) + 50)
+    while True:
+        s = Nall.T @ x - b
+        viol = np.where(np.isin(np.arange(m), A), 0.0, s / norms)
+        p = int(np.argmin(viol))
+        if viol[p] >= -1e3 * eps * max(1.0, float(np.abs(x).max())):
+            return x
+        n_p, u_p = Nall[:, p], 0.0
+        while True:
+            it += 1
+            if it > max_iter:
+                raise RuntimeError("Goldfarb-Idnani: iteration limit")
+            if A:
+                NA = Nall[:, A]
+                W = psolve(NA)                                         # P^-1 N
+                r = np.linalg.solve(NA.T @ W, W.T @ n_p)               # N* n_p
+                z = psolve(n_p) - W @ r                                # H n_p
+            else:
+                r, z = np.zeros(0), psolve(n_p)
+            t1, k = np.inf, -1
+            for idx in range(len(A)):
+                if r[idx] > 0 and u[idx] / r[idx] < t1:
+                    t1, k = u[idx] / r[idx], idx
+            zn = float(z @ n_p)
+            s_p = float(n_p @ x - b[p])
+            t2 = -s_p / zn if zn > eps * max(1.0, float(n_p @ psolve(n_p))) else np.inf
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                raise ValueError("constraints are inconsistent, no solution")   # quadprog's message
+            if not np.isfinite(t2):                                            # step in the dual space only
+                u = u - t * r
+                u_p += t
+                A.pop(k); u = np.delete(u, k)
+                continue
+            x = x + t * z
+            u = u - t * r
+            u_p += t
+            if t == t2:                                                        # full step: p becomes active
+                A.append(p); u = np.append(u, u_p)
+                break
+            A.pop(k); u = np.delete(u, k)                                      # partial step: k leaves, p stays violated
+
+
+def solve_qp(P, q, G=None, h=None, solver="quadprog", verbose=False, **kwargs):
+    """The one qpsolvers entry point the reference uses (stm.py:271), on the restated Goldfarb-Idnani method."""
+    n = len(np.asarray(q).ravel())
+    if G is None:
+        G, h = np.zeros((0, n)), np.zeros(0)
+    return solve_qp_goldfarb_idnani(P, q, G, h)
+
+
+def nnls_weights(P, q):
+    """The same minimiser in its non-negative least-squares form (w = -x = argmin_{w >= 0} || R w - R^-T q ||, P = R'R):
+    what the device solver (stm_spectral.h, Lawson-Hanson) computes; kept here as the cross-check of the two forms."""
     from scipy.optimize import nnls
+    R = np.linalg.cholesky(0.5 * (P + P.T)).T
+    return nnls(R, np.linalg.solve(R.T, q))[0]
+
+
+def recover_l2_weights(Q, anchor, rows=None):
+    """stm.py:239-285: P = M M', and per term i the QP min 1/2 x'Px + (M y_i)'x, x <= 0, weights[i] = -x; one-hot rows
+    for the anchor terms (stm.py:261-264).  `rows`: only these terms (the others stay zero)."""
     anchor = np.intp(anchor)
     M = Q[anchor]
     P = M @ M.T
-    R = np.linalg.cholesky(P).T                      # P = R^T R
     Vk, K = Q.shape[0], len(anchor)
+    G, h = np.eye(K), np.zeros(K)
+    L = np.linalg.cholesky(P)
+    Pinv = np.linalg.solve(L.T, np.linalg.solve(L, np.eye(K)))
+    Pinv = 0.5 * (Pinv + Pinv.T)
     weights = np.zeros((Vk, K))
-    for i in range(Vk):
+    for i in (range(Vk) if rows is None else rows):
         hit = np.where(anchor == i)[0]
         if len(hit):
             weights[i, hit] = 1
         else:
-            q = M @ Q[i]
-            weights[i] = nnls(R, np.linalg.solve(R.T, q))[0]
+            weights[i] = -solve_qp_goldfarb_idnani(P, M @ Q[i], G, h, Pinv=Pinv)
+    return weights
+
+
+def recover_l2(Q, anchor, wprob):
+    """stm.py:229-296."""
+    weights = recover_l2_weights(Q, anchor)
     A = weights.T * wprob
     A = A.T / np.sum(A, axis=1)
     return A.T

@@ -15,7 +15,6 @@
 #include "stm_mstep.h"
 #include "stm_betass.h"
 #include "stm_post.h"
-#include "stm_post_v1.h"
 #include "stm_post_big.h"
 #include "stm_solver.h"
 
@@ -284,7 +283,7 @@ static int plan_solver(stm_handle *h) {
 static int build_word_major(stm_handle *h) {
     const int64_t N = h->N, nnz = h->nnz;
     const size_t R = (size_t)h->A * (size_t)h->V;
-    const int64_t gdocs = std::max<int64_t>(1, (int64_t)env_int("STM_BETASS_GROUP_KB", stm::BETASS_GROUP_BYTES >> 10) * 1024 / ((int64_t)h->K * 8));
+    const int64_t gdocs = std::max<int64_t>(1, stm::BETASS_GROUP_BYTES / ((int64_t)h->K * 8));
     int64_t G = std::max<int64_t>(1, (N + gdocs - 1) / gdocs);
     G = std::min<int64_t>(G, 64);
     G = std::min<int64_t>(G, std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)std::max<size_t>(R * (size_t)h->K, 1)));   // <= 2 GB of partial sums
@@ -714,19 +713,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         const bool rem = n > 16 && n % 16 == 1 && env_int("STM_POST_REM", 1);
         const int nb = rem ? n / 16 : (n + 15) / 16;
         const bool dbg = pp.nu_out != nullptr || pp.prof != nullptr || pp.debug_flags != 0;
-        const bool v1 = env_int("STM_POST_IMPL", 0) == 1;   // the round-2 kernel, for A/B runs
         PostFn pf;
-        if (v1) {
-            const bool dumps = pp.nu_out != nullptr;
-            if (rem)
-                pf = dumps ? (nb == 1 ? stm::post_kernel_v1<1, 1, true> : nb == 2 ? stm::post_kernel_v1<2, 1, true> : stm::post_kernel_v1<3, 1, true>)
-                           : (nb == 1 ? stm::post_kernel_v1<1, 1, false> : nb == 2 ? stm::post_kernel_v1<2, 1, false> : stm::post_kernel_v1<3, 1, false>);
-            else
-                pf = dumps ? (nb <= 1 ? stm::post_kernel_v1<1, 0, true> : nb == 2 ? stm::post_kernel_v1<2, 0, true>
-                              : nb == 3 ? stm::post_kernel_v1<3, 0, true> : stm::post_kernel_v1<4, 0, true>)
-                           : (nb <= 1 ? stm::post_kernel_v1<1, 0, false> : nb == 2 ? stm::post_kernel_v1<2, 0, false>
-                              : nb == 3 ? stm::post_kernel_v1<3, 0, false> : stm::post_kernel_v1<4, 0, false>);
-        } else if (rem) {
+        if (rem) {
             pf = dbg ? (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, true> : stm::post_kernel<3, 1, POST_WPE, true>)
                      : (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, false> : stm::post_kernel<3, 1, POST_WPE, false>);
         } else {
@@ -736,12 +724,12 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
                         : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
         }
         const bool big = K > stm::PT;   // two topics per lane (stm_post_big.h)
-        pp.MLD = big ? stm::post_big_mld(n) : stm::post_v1_mld(n);
+        pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
         const int nbb = (n + 15) / 16;
         const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
                            : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
         const PostFn pfn = big ? pfb : pf;
-        const size_t lds = (big ? stm::post_big_lds_doubles(n) : v1 ? stm::post_v1_lds_doubles(n, pp.MLD, K) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
+        const size_t lds = (big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
         pp.lds_doubles = (int)(lds / sizeof(double));
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
@@ -754,26 +742,22 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         }
         pp.first = 0; pp.count = h->N;
         // nu is summed per workgroup in a slab of its own (post_kernel: plain read-modify-write, nrep = grid) or
-        // atomically into nrep replicas (post_kernel_v1, post_big_kernel); reduce_sigma_kernel adds them in a fixed order
-        nrep = (big || v1) ? h->nrep : (int)grid;
+        // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
+        nrep = big ? h->nrep : (int)grid;
         const int nbc = (n + 15) / 16;
-        slab = (big || v1) ? (size_t)n * n : (size_t)(nbc * (nbc + 1) / 2) * 256;   // post_kernel: accumulator-tile layout
+        slab = big ? (size_t)n * n : (size_t)(nbc * (nbc + 1) / 2) * 256;   // post_kernel: accumulator-tile layout
         if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
         HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
         pp.sigma_part = h->d_sigma_part; pp.nrep = nrep;
         pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
         hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
-        if (!big && !v1 && h->nnz > 0) {   // beta_ss from the r_dw the post kernel left behind (stm_betass.h)
+        if (!big && h->nnz > 0) {   // beta_ss from the r_dw the post kernel left behind (stm_betass.h)
             stm::BetaSsParams bp{};
             bp.K = K; bp.G = h->G; bp.R = (int64_t)h->A * h->V; bp.cptr = h->d_cptr; bp.wm_doc = h->d_wm_doc; bp.rw = h->d_rw;
             bp.theta = h->d_theta; bp.betaT = h->d_betaT; bp.part = h->d_bss_part; bp.beta_ssT = h->d_beta_ssT;
-            const int rows = env_int("STM_BETASS_ROWS", stm::BETASS_ROWS_DEFAULT), depth = env_int("STM_BETASS_DEPTH", 8);
-            const int64_t wpg = (bp.R + rows - 1) / rows, bpg = (wpg + 3) / 4;
-            auto fn = rows == 4 ? (depth == 16 ? stm::beta_ss_part_kernel<16, 4> : stm::beta_ss_part_kernel<8, 4>)
-                    : rows == 16 ? (depth == 16 ? stm::beta_ss_part_kernel<16, 16> : stm::beta_ss_part_kernel<8, 16>)
-                    : (depth == 16 ? stm::beta_ss_part_kernel<16, 8> : stm::beta_ss_part_kernel<8, 8>);
-            hipLaunchKernelGGL(fn, dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+            const int64_t wpg = (bp.R + stm::BETASS_ROWS - 1) / stm::BETASS_ROWS, bpg = (wpg + 3) / 4;
+            hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
             hipLaunchKernelGGL(stm::beta_ss_reduce_kernel, dim3((unsigned)((bp.R * K + 255) / 256)), dim3(256), 0, h->stream, bp);
             HIP_TRY(hipGetLastError());
         }

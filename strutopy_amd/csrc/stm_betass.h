@@ -34,20 +34,20 @@ struct BetaSsParams {
 };
 
 constexpr int BETASS_GROUP_BYTES = 1 << 20;   // theta bytes per document group
-constexpr int BETASS_ROWS_DEFAULT = 4;        // rows per wave
+constexpr int BETASS_ROWS = 4;                // rows per wave (4 / 8 / 16 and 8 / 16 loads in flight measured: 0.56 - 0.73 ms at configs[1])
 
-// One wave per (BETASS_ROWS rows, group), lane = topic; blockIdx is group-major.  A cell's (document, r) pairs are fetched
+// One wave per (ROWS rows, group), lane = topic; blockIdx is group-major.  A cell's (document, r) pairs are fetched
 // lane-parallel -- the next cell's while the current one is consumed -- and handed out with v_readlane, DEPTH theta rows in flight.
-template <int DEPTH, int BETASS_ROWS>
+template <int DEPTH, int ROWS>
 __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
     const int lane = threadIdx.x & 63;
     const int K = P.K, G = P.G;
-    const int64_t R = P.R, wpg = (R + BETASS_ROWS - 1) / BETASS_ROWS;     // waves per group
+    const int64_t R = P.R, wpg = (R + ROWS - 1) / ROWS;     // waves per group
     const int64_t bpg = (wpg + 3) / 4;                                      // blocks per group
     const int g = (int)(blockIdx.x / bpg);
     const int64_t wv = (blockIdx.x % bpg) * 4 + (threadIdx.x >> 6);
     if (wv >= wpg) return;
-    const int64_t r0 = wv * BETASS_ROWS, r1 = r0 + BETASS_ROWS < R ? r0 + BETASS_ROWS : R;
+    const int64_t r0 = wv * ROWS, r1 = r0 + ROWS < R ? r0 + ROWS : R;
     const int kl = lane < K ? lane : 0;
     const double *th0 = P.theta + kl;
     // lane q <= rows: the cell boundaries cp[(r0 + q) * G + g] and, in the next lane block, their ends

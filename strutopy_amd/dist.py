@@ -17,9 +17,10 @@ cancel too many digits.
 Layers
   * host group  -- rendezvous + small host collectives between the ranks of one
     node.  ``TcpGroup`` is the product's: Python stdlib sockets only (no
-    PyTorch), a star through rank 0, found through ``STM_RDZV_PORT`` or a
-    rendezvous file keyed by MASTER_ADDR / MASTER_PORT.  ``GlooGroup`` wraps an
-    initialised torch.distributed process group (CPU test rig).
+    PyTorch, no pickle), a star through rank 0, found through ``STM_RDZV_PORT`` or a
+    private rendezvous file keyed by MASTER_ADDR / MASTER_PORT, authenticated by the
+    run's shared secret.  (tests/_gloo_rig.py has the same interface over
+    torch.distributed/gloo for the CPU test rig.)
   * communicators used by STM
       ``SingleComm``  world size 1
       ``RcclComm``    the product path: RCCL all-reduce on the device-resident
@@ -30,9 +31,11 @@ Layers
                       device collectives (CPU tests) and as a collective
                       fallback when RCCL cannot initialise
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
+import stat
 import struct
 import tempfile
 import time
@@ -56,8 +59,118 @@ def shard_bounds(indptr, world):
 
 
 # ------------------------------------------------------------------------------ host groups
+# Wire format of the host group.  Nothing received is ever unpickled: a frame is an 8-byte length (capped) and a body in
+# the small tagged encoding below (None, bool, int, float, str, bytes, list, tuple, dict, ndarray), and a connection is
+# only used after both ends have proved, with an HMAC over a fresh nonce, that they hold the run's shared secret
+# (STM_RDZV_SECRET from the launcher, or a 0600 file in a 0700 directory owned by this user).
+_MAGIC = b"STMRDZV2"
+_MAX_FRAME = 1 << 31
+
+
+def _enc(obj, out):
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b"I" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"D" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        raw = obj.encode("utf-8")
+        out.append(b"S" + struct.pack("<Q", len(raw)) + raw)
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"B" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"L" if isinstance(obj, list) else b"U") + struct.pack("<Q", len(obj)))
+        for x in obj:
+            _enc(x, out)
+    elif isinstance(obj, dict):
+        out.append(b"M" + struct.pack("<Q", len(obj)))
+        for k, v in obj.items():
+            _enc(str(k), out)
+            _enc(v, out)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError("host group: object arrays are not sent")
+        a = np.ascontiguousarray(obj)
+        dt = a.dtype.str.encode("ascii")
+        out.append(b"A" + struct.pack("<BB", len(dt), a.ndim) + dt + struct.pack(f"<{a.ndim}q", *a.shape))
+        out.append(a.tobytes())
+    else:
+        raise TypeError(f"host group: cannot send {type(obj).__name__}")
+
+
+def _encode(obj):
+    out = []
+    _enc(obj, out)
+    return b"".join(out)
+
+
+def _dec(buf, pos):
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag in (b"T", b"F"):
+        return tag == b"T", pos
+    if tag == b"I":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"D":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"S", b"B"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("host group: truncated frame")
+        raw = bytes(buf[pos:pos + n])
+        return (raw.decode("utf-8") if tag == b"S" else raw), pos + n
+    if tag in (b"L", b"U", b"M"):
+        (n,) = struct.unpack_from("<Q", buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("host group: truncated frame")
+        items = []
+        for _ in range(n if tag != b"M" else 2 * n):
+            x, pos = _dec(buf, pos)
+            items.append(x)
+        if tag == b"L":
+            return items, pos
+        if tag == b"U":
+            return tuple(items), pos
+        return dict(zip(items[0::2], items[1::2])), pos
+    if tag == b"A":
+        ld, nd = struct.unpack_from("<BB", buf, pos)
+        pos += 2
+        dt = np.dtype(bytes(buf[pos:pos + ld]).decode("ascii"))
+        pos += ld
+        if dt.hasobject or nd > 8:
+            raise ValueError("host group: bad array header")
+        shape = struct.unpack_from(f"<{nd}q", buf, pos)
+        pos += 8 * nd
+        cnt = 1
+        for d in shape:
+            if d < 0:
+                raise ValueError("host group: bad array shape")
+            cnt *= d
+        nbytes = cnt * dt.itemsize
+        if nbytes > len(buf) - pos:
+            raise ValueError("host group: truncated frame")
+        return np.frombuffer(buf, dtype=dt, count=cnt, offset=pos).reshape(shape).copy(), pos + nbytes
+    raise ValueError("host group: unknown tag")
+
+
+def _decode(buf):
+    obj, pos = _dec(buf, 0)
+    if pos != len(buf):
+        raise ValueError("host group: trailing bytes")
+    return obj
+
+
 def _send_msg(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    data = _encode(obj)
+    if len(data) > _MAX_FRAME:
+        raise ValueError("host group: frame too large")
     sock.sendall(struct.pack("<Q", len(data)) + data)
 
 
@@ -73,13 +186,49 @@ def _recv_exact(sock, n):
 
 def _recv_msg(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > _MAX_FRAME:
+        raise ConnectionError("host group: frame length out of range")
+    return _decode(_recv_exact(sock, n))
+
+
+def _private_dir():
+    """A directory only this user can enter (created 0700; refused when it is a link, someone else's or wider open)."""
+    d = os.path.join(tempfile.gettempdir(), f"stm_rdzv_{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (stat.S_IMODE(st.st_mode) & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not private to this user")
+    return d
 
 
 def rendezvous_file(addr, port, run_id=""):
-    """Where rank 0 publishes its listening port when STM_RDZV_PORT is not given (ranks share one node)."""
+    """Where rank 0 publishes its listening port and the run's secret when the launcher exported neither
+    STM_RDZV_PORT nor STM_RDZV_SECRET (the ranks share one node and one user)."""
     tag = f"{addr}_{port}_{run_id}".replace("/", "_").replace(":", "_")
-    return os.path.join(tempfile.gettempdir(), f"stm_rdzv_{tag}")
+    return os.path.join(_private_dir(), tag)
+
+
+def _publish(path, text):
+    tmp = f"{path}.{os.getpid()}.tmp"
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "w") as fh:
+        fh.write(text)
+    os.replace(tmp, path)      # atomic
+
+
+def _read_private(path):
+    st = os.lstat(path)
+    if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (stat.S_IMODE(st.st_mode) & 0o077):
+        raise PermissionError(f"rendezvous file {path} is not private to this user")
+    with open(path) as fh:
+        return fh.read().split()
+
+
+def _mac(secret, *parts):
+    return hmac.new(secret, b"".join(parts), hashlib.sha256).digest()
 
 
 class TcpGroup:
@@ -90,7 +239,7 @@ class TcpGroup:
     """
     kind = "tcp"
 
-    def __init__(self, rank, size, addr="127.0.0.1", port=None, rdzv_file=None, timeout=600.0):
+    def __init__(self, rank, size, addr="127.0.0.1", port=None, rdzv_file=None, timeout=600.0, secret=None):
         self.rank, self.size = int(rank), int(size)
         self._peers = []       # rank 0: sockets of ranks 1..size-1 (index r-1)
         self._root = None      # other ranks: socket to rank 0
@@ -99,18 +248,20 @@ class TcpGroup:
             return
         if port is None and rdzv_file is None:
             raise ValueError("TcpGroup needs a port or a rendezvous file")
+        if secret is None and os.environ.get("STM_RDZV_SECRET"):
+            secret = bytes.fromhex(os.environ["STM_RDZV_SECRET"])
+        if secret is None and rdzv_file is None:
+            rdzv_file = rendezvous_file(addr, port, "secret")     # a fixed port without a secret: the file carries the secret
         deadline = time.time() + timeout
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, int(port) if port is not None else 0))
             srv.listen(self.size)
-            token = os.urandom(8).hex()
-            if port is None:
-                tmp = rdzv_file + f".{os.getpid()}.tmp"
-                with open(tmp, "w") as fh:
-                    fh.write(f"{srv.getsockname()[1]} {token}\n")
-                os.replace(tmp, rdzv_file)      # atomic publish
+            if rdzv_file is not None:
+                if secret is None:
+                    secret = os.urandom(32)
+                _publish(rdzv_file, f"{srv.getsockname()[1]} {secret.hex()}\n")
                 self._file = rdzv_file
             peers = {}
             srv.settimeout(1.0)
@@ -121,15 +272,20 @@ class TcpGroup:
                     c, _ = srv.accept()
                 except socket.timeout:
                     continue
-                c.settimeout(timeout)
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                hello = _recv_msg(c)
-                if not (isinstance(hello, tuple) and len(hello) == 3 and hello[0] == "stm-hello" and hello[2] == self.size
-                        and 0 < hello[1] < self.size and hello[1] not in peers):
+                try:       # a stray, stale or hostile connection must not take the rendezvous down
+                    c.settimeout(5.0)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    hello = _recv_exact(c, 64)
+                    magic, (r, sz), nonce, mac = hello[:8], struct.unpack("<II", hello[8:16]), hello[16:32], hello[32:]
+                    if (magic != _MAGIC or sz != self.size or not 0 < r < self.size or r in peers
+                            or not hmac.compare_digest(mac, _mac(secret, hello[:32]))):
+                        c.close()
+                        continue
+                    c.sendall(_MAGIC + _mac(secret, b"welcome", nonce))
+                    c.settimeout(timeout)
+                    peers[r] = c
+                except (OSError, ConnectionError, struct.error, ValueError):
                     c.close()
-                    continue
-                _send_msg(c, ("stm-welcome", token))
-                peers[hello[1]] = c
             srv.close()
             self._peers = [peers[r] for r in range(1, self.size)]
             if self._file:
@@ -141,25 +297,27 @@ class TcpGroup:
             while True:
                 if time.time() > deadline:
                     raise TimeoutError("rendezvous: rank 0 did not appear")
-                p, token = port, None
-                if p is None:
+                p, sec = port, secret
+                if rdzv_file is not None:
                     try:
-                        with open(rdzv_file) as fh:
-                            p, token = fh.read().split()
+                        fp, fs = _read_private(rdzv_file)
+                        p, sec = (fp if port is None else port), (bytes.fromhex(fs) if secret is None else secret)
                     except (OSError, ValueError):
                         time.sleep(0.05)
                         continue
                 try:
                     s = socket.create_connection((addr, int(p)), timeout=5.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    _send_msg(s, ("stm-hello", self.rank, self.size))
-                    reply = _recv_msg(s)
-                    if isinstance(reply, tuple) and reply[0] == "stm-welcome" and (token is None or reply[1] == token):
+                    nonce = os.urandom(16)
+                    head = _MAGIC + struct.pack("<II", self.rank, self.size) + nonce
+                    s.sendall(head + _mac(sec, head))
+                    reply = _recv_exact(s, 40)
+                    if reply[:8] == _MAGIC and hmac.compare_digest(reply[8:], _mac(sec, b"welcome", nonce)):
                         s.settimeout(timeout)
                         self._root = s
                         break
                     s.close()
-                except (OSError, ConnectionError, pickle.UnpicklingError, struct.error):
+                except (OSError, ConnectionError, struct.error):
                     pass
                 time.sleep(0.05)       # stale file / rank 0 not listening yet: read again
 
@@ -204,41 +362,6 @@ class TcpGroup:
         if self._root is not None:
             self._root.close()
         self._peers, self._root = [], None
-
-
-class GlooGroup:
-    """The same interface over an initialised torch.distributed (gloo) process group (CPU test rig)."""
-    kind = "gloo"
-
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self._torch, self._dist = torch, dist
-        self.rank, self.size = dist.get_rank(), dist.get_world_size()
-        self._group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
-
-    def allgather(self, obj):
-        out = [None] * self.size
-        self._dist.all_gather_object(out, obj, group=self._group)
-        return out
-
-    def allreduce(self, buf, op="sum"):
-        t = self._torch.from_numpy(np.array(buf, dtype=np.float64, copy=True))
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX, group=self._group)
-        return t.numpy()
-
-    def broadcast(self, obj, src=0):
-        box = [obj if self.rank == src else None]
-        self._dist.broadcast_object_list(box, src=src, group=self._group)
-        return box[0]
-
-    def barrier(self):
-        self._dist.barrier(group=self._group)
-
-    def close(self):
-        pass
 
 
 def init_from_env(timeout=600.0):
@@ -336,8 +459,3 @@ class RcclComm(_GroupComm):
 
     def allreduce_small(self, engine, buf):
         return engine.allreduce_small(buf)
-
-
-def GlooComm():
-    """HostComm over torch.distributed/gloo (tests/test_dist_gloo.py)."""
-    return HostComm(GlooGroup())

@@ -11,7 +11,8 @@ Same statements as the reference, with the V x V work on the GPU behind the C-AB
 
 The reference hands the per-term QP to qpsolvers/quadprog.  It is the strictly convex non-negative least-squares
 problem min || M^T w - y ||, w >= 0 (w = -x), whose minimiser does not depend on the solver; it is solved on the device
-by a Lawson-Hanson active set, one thread per term (`solve_weights` below -- SciPy's nnls -- is what the tests check it against).  Quirks of the reference that are kept: Q is NOT row-normalised
+by a Lawson-Hanson active set, one thread per term (the tests hold it against quadprog's Goldfarb-Idnani method as restated
+in oracle/spectral_oracle.py and against the QP's KKT conditions).  Quirks of the reference that are kept: Q is NOT row-normalised
 (sklearn's normalize(copy=False) works on a discarded CSR copy of the CSC product), fastAnchor uses column sums of
 squares and never projects row 0, the first anchor's row of the caller's Q is rescaled, no sum-to-one constraint,
 and the final division by the TOTAL sum leaves every row of beta summing to 1 / K.
@@ -53,23 +54,6 @@ def gram_inputs(corpus, keep):
                 word_ptr=word_ptr, word_doc=doc[order].astype(np.int32), word_h=np.ascontiguousarray(h[order]), hhat=hhat)
 
 
-def solve_weights(q, anchor):
-    """recover_l2's loop (stm.py:257-285): weights[i] = -argmin_{x <= 0} 1/2 x'Px + q_i'x, one-hot rows for the anchors."""
-    from scipy.optimize import nnls
-    anchor = np.intp(anchor)
-    P = q[anchor]                                                        # M M^T
-    R = np.linalg.cholesky(0.5 * (P + P.T)).T                            # P = R^T R
-    rhs = np.linalg.solve(R.T, q.T)                                      # R^-T q_i for every term
-    weights = np.zeros_like(q)
-    isanchor = np.zeros(len(q), dtype=bool)
-    isanchor[anchor] = True
-    for i in np.flatnonzero(~isanchor):
-        weights[i] = nnls(R, rhs[:, i])[0]
-    for k, a in enumerate(anchor):                                       # vec[np.where(anchor == i)] = 1
-        weights[a, anchor == a] = 1
-    return weights
-
-
 def spectral_init(corpus, K, V, maxV=5000, verbose=True, engine=None, details=None):
     """Drop-in for spectral_init(corpus, K, V, maxV) (stm.py:30-85); `corpus` is the BoW list or a PackedCorpus,
     `engine` a strutopy_amd.engine.HipEstepEngine (one is created on GPU 0 when omitted)."""
@@ -88,10 +72,7 @@ def spectral_init(corpus, K, V, maxV=5000, verbose=True, engine=None, details=No
         anchor = engine.spectral_anchors(K)
         if verbose:
             print("Recover values for beta")
-        if hasattr(engine, "spectral_weights"):
-            weights = engine.spectral_weights(anchor)          # q_i = M y_i and the per-term QPs, on the device
-        else:                                                    # engines without it (the CPU test double): SciPy
-            weights = solve_weights(engine.spectral_project(anchor), anchor)
+        weights = engine.spectral_weights(anchor)              # q_i = M y_i and the per-term QPs, on the device
         if details is not None:
             details.update(wprob=wprob, keep=keep, anchor=anchor.astype(np.float64), weights=weights)
         engine.spectral_release()

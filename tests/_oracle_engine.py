@@ -105,4 +105,5 @@ class OracleEngine:
 
     def spectral_q_rows(self, rows): return self._sq0[np.intp(rows)].copy()
     def spectral_project(self, anchor): return self._sq0 @ self._sq0[np.intp(anchor)].T
+    def spectral_weights(self, anchor): return self._so.recover_l2_weights(self._sq0, anchor)   # Goldfarb-Idnani, per term
     def spectral_release(self): self._sq0 = None

@@ -37,7 +37,8 @@ def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="
 
         import torch.distributed as tdist
         tdist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
-        comm = sdist.GlooComm()
+        from _gloo_rig import GlooComm
+        comm = GlooComm()
     else:   # the product's host group: stdlib sockets, rendezvous file keyed by MASTER_PORT
         comm = sdist.HostComm(sdist.init_from_env(timeout=120))
     lo, hi = sdist.shard_bounds(full.indptr, world)[rank]
@@ -150,3 +151,62 @@ def test_product_comm_path_is_torch_free():
             "assert 'torch' not in sys.modules, 'torch was imported'" % ROOT)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
     subprocess.run([sys.executable, "-c", code], check=True, env=env)
+
+
+def _tcp_rank(rank, world, port, secret, q):
+    sys.path.insert(0, ROOT)
+    from strutopy_amd import dist as sdist
+    g = sdist.TcpGroup(rank, world, "127.0.0.1", port=port, timeout=60, secret=secret)
+    out = g.allgather((rank, np.arange(3) * rank, {"a": "b" * rank, "n": None}))
+    red = g.allreduce(np.full(4, float(rank + 1)))
+    q.put((rank, [o[0] for o in out], [o[1].tolist() for o in out], out[1][2], red.tolist()))
+    g.close()
+
+
+def test_tcp_group_survives_garbage_and_rejects_the_wrong_secret():
+    """The rendezvous of the host group: nothing is unpickled, a peer must prove the shared secret, and a
+    port scan / stale rank / hostile peer on the listening port neither joins nor takes rank 0 down."""
+    import multiprocessing as mp
+    import struct
+    import time
+    from strutopy_amd import dist as sdist
+    ctx = mp.get_context("spawn")
+    port, secret = _free_port(), os.urandom(32)
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_tcp_rank, args=(0, 2, port, secret, q))
+    p0.start()
+    time.sleep(1.0)
+    for payload in (b"", b"GET / HTTP/1.0\r\n\r\n", os.urandom(64),                       # scan, stray client, noise
+                    struct.pack("<Q", 1 << 60) + b"x" * 8,                                     # an absurd frame length
+                    sdist._MAGIC + struct.pack("<II", 1, 2) + b"n" * 16 + b"\0" * 32):       # right shape, no secret
+        s = socket.create_connection(("127.0.0.1", port), timeout=5)
+        s.sendall(payload)
+        s.close()
+    with pytest.raises(TimeoutError):      # the wrong secret never gets in
+        sdist.TcpGroup(1, 2, "127.0.0.1", port=port, timeout=1.5, secret=os.urandom(32))
+    p1 = ctx.Process(target=_tcp_rank, args=(1, 2, port, secret, q))
+    p1.start()
+    got = sorted(q.get(timeout=60) for _ in range(2))
+    p0.join(30); p1.join(30)
+    assert p0.exitcode == 0 and p1.exitcode == 0
+    for r, ranks, arrs, d, red in got:
+        assert ranks == [0, 1] and arrs == [[0, 0, 0], [0, 1, 2]] and d == {"a": "b", "n": None} and red == [3.0] * 4
+
+
+def test_host_group_wire_format_round_trips_without_pickle():
+    from strutopy_amd import dist as sdist
+    obj = (1, -2.5, True, None, "x", b"\x00\xff", [np.arange(6, dtype=np.int32).reshape(2, 3), np.array(["a", "bc"])],
+           {"k": (np.float64(3.0), np.int64(7))})
+    back = sdist._decode(sdist._encode(obj))
+    assert back[:6] == obj[:6] and np.array_equal(back[6][0], obj[6][0]) and back[6][0].dtype == np.int32
+    assert np.array_equal(back[6][1], obj[6][1]) and back[7] == {"k": (3.0, 7)}
+    with pytest.raises(TypeError):
+        sdist._encode(object())
+    with pytest.raises(ValueError):
+        sdist._decode(b"A\x03\x01|O8" + struct_pack_q(1))          # an object-dtype array header is refused
+    assert "pickle" not in open(sdist.__file__).read().replace("no pickle", "").replace("unpickled", "")
+
+
+def struct_pack_q(n):
+    import struct
+    return struct.pack("<q", n)

@@ -3,8 +3,9 @@
 CPU: the NumPy restatement (oracle/spectral_oracle.py) and the host side of strutopy_amd.spectral (with the oracle
 standing in for the device steps) against goldens made by running the reference's own gram / fastAnchor /
 recover_l2 / spectral_init (tools/make_golden.py spectral_c1 spectral_wiki).  gram and fastAnchor are the
-reference as imported; recover_l2's QP went through the stand-in solve_qp of tools/refshim (qpsolvers / quadprog are
-absent from the image; the QP is strictly convex, its minimiser solver-independent) -- the fixtures say so (`qp_solver`).
+reference as imported; recover_l2's solve_qp call reaches quadprog's algorithm -- the dual active-set method of Goldfarb &
+Idnani (1983) -- as restated in oracle/spectral_oracle.py (qpsolvers / quadprog themselves are absent from the image; the
+fixtures say so in `qp_solver`).
 GPU: the same checks through the C-ABI (stm_spectral_*)."""
 import numpy as np
 import pytest
@@ -72,25 +73,49 @@ def test_host_side_with_the_oracle_engine_and_the_stm_surface():
     assert np.isfinite(m.bound)
 
 
-def test_qp_step_is_the_nonnegative_least_squares_fit():
-    """recover_l2's QP (stm.py:271-285: min 1/2 x'Px + q'x, x <= 0, weights = -x) against its KKT conditions."""
-    from strutopy_amd.spectral import solve_weights
-    rng = np.random.default_rng(0)
-    Vk, K = 120, 7
-    Q = np.abs(rng.normal(size=(Vk, Vk))) * (rng.random((Vk, Vk)) < 0.3)
-    anchor = rng.choice(Vk, K, replace=False)
+def _kkt(P, q, w, tol=1e-9):
+    """KKT conditions of min 1/2 x'Px + q'x, x <= 0 at x = -w (stm.py:271-285)."""
+    grad = P @ w - q                                   # gradient of 1/2 w'Pw - q'w
+    scale = max(1.0, float(np.abs(q).max()))
+    free = w > 1e-12 * max(1.0, float(np.abs(w).max()))   # a weight the active-set method left at rounding level is a bound one
+    return bool(np.all(w >= -1e-15) and np.all(grad >= -tol * scale) and np.all(np.abs(grad[free]) <= tol * scale))
+
+
+def test_goldfarb_idnani_restatement_on_known_answers():
+    """The restated quadprog algorithm on QPs with answers known in closed form, incl. the worked example of the paper
+    (Goldfarb & Idnani 1983, section 5; also the example of R's solve.QP documentation)."""
+    from oracle.spectral_oracle import solve_qp_goldfarb_idnani as gi
+    # solve.QP's example: min -d'b + 1/2 b'Db, D = I, d = (0, 5, 0), A'b >= b0
+    Amat = np.array([[-4.0, -3.0, 0.0], [2.0, 1.0, 0.0], [0.0, -2.0, 1.0]]).T        # columns of R's Amat
+    b0 = np.array([-8.0, 2.0, 0.0])
+    x = gi(np.eye(3), -np.array([0.0, 5.0, 0.0]), -Amat.T, -b0)          # Amat' b >= b0  <=>  (-Amat') b <= -b0
+    assert np.allclose(x, [0.4761905, 1.0476190, 2.0952381], atol=1e-7)              # the documented solution
+    # unconstrained minimum inside the feasible set / on one face / at a vertex
+    P = np.array([[2.0, 0.5], [0.5, 1.0]])
+    assert np.allclose(gi(P, np.array([1.0, 1.0]), np.eye(2), np.zeros(2)), -np.linalg.solve(P, [1.0, 1.0]))
+    assert np.allclose(gi(P, np.array([-1.0, 1.0]), np.eye(2), np.zeros(2)), [0.0, -1.0])
+    assert np.allclose(gi(P, np.array([-1.0, -2.0]), np.eye(2), np.zeros(2)), [0.0, 0.0])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_qp_step_goldfarb_idnani_equals_the_least_squares_form(name):
+    """recover_l2's QP on the fixtures' own inputs: quadprog's algorithm (restated) and the non-negative least-squares form
+    the device solves give the same weights to 1e-10, and both satisfy the KKT conditions."""
+    from oracle import spectral_oracle as so
+    g = load_golden(name)
+    c = _corpus(g)
+    wprob, keep = so.word_probabilities(c.indptr, c.indices, c.counts)
+    Q = so.fast_anchor(so.gram(c.indptr, c.indices, c.counts, keep), int(g["K"]))[1]
+    anchor = np.intp(g["anchor"])
     M = Q[anchor]
-    q = Q @ M.T
-    w = solve_weights(q, anchor)
     P = M @ M.T
-    for i in range(Vk):
-        if i in anchor:
-            assert w[i].sum() == 1 and w[i, list(anchor).index(i)] == 1
-            continue
-        grad = P @ w[i] - q[i]                    # gradient of 1/2 w'Pw - q'w
-        assert np.all(w[i] >= 0)
-        assert np.all(grad >= -1e-9 * max(1.0, np.abs(q[i]).max()))                 # dual feasibility
-        assert np.all(np.abs(grad[w[i] > 0]) <= 1e-9 * max(1.0, np.abs(q[i]).max()))  # complementarity
+    rows = [i for i in np.linspace(0, len(keep) - 1, 160 if name == "spectral_c1" else 60).astype(np.int64) if i not in set(anchor)]
+    w_gi = so.recover_l2_weights(Q, anchor, rows=rows)
+    for i in rows:
+        q = M @ Q[i]
+        w_ls = so.nnls_weights(P, q)
+        assert np.max(np.abs(w_gi[i] - w_ls)) <= 1e-10 * max(1.0, float(np.abs(w_ls).max())), (name, int(i))
+        assert _kkt(P, q, w_gi[i]) and _kkt(P, q, w_ls)
 
 
 @pytest.mark.gpu
@@ -114,12 +139,17 @@ def test_device_gram_anchors_and_beta_match_the_reference(name):
     _check_parts(g, keep, wprob, anchor, q_rows)
     if "Q_caller_anchor_rows" in g.files:
         assert np.allclose(e.spectral_q_rows(anchor), g["Q_caller_anchor_rows"], rtol=1e-12, atol=1e-15)
-    # the per-term QPs on the device against SciPy's NNLS on the same inputs (and the KKT conditions of the QP)
-    from strutopy_amd.spectral import solve_weights
+    # the per-term QPs on the device against quadprog's algorithm (restated, a sample of terms) on the same inputs, and
+    # against the KKT conditions of the QP (every term)
+    from oracle import spectral_oracle as so
     q = e.spectral_project(anchor)
-    w_dev, w_ref = e.spectral_weights(anchor), solve_weights(q, anchor)
-    assert w_dev.min() >= 0 and np.allclose(w_dev, w_ref, rtol=1e-8, atol=1e-10 * np.abs(w_ref).max())
+    w_dev = e.spectral_weights(anchor)
     P = q[np.intp(anchor)]
+    sample = [i for i in np.linspace(0, len(q) - 1, 80).astype(np.int64) if i not in set(np.intp(anchor))]
+    for i in sample:
+        w_gi = -so.solve_qp_goldfarb_idnani(P, q[i], np.eye(K), np.zeros(K))
+        assert np.max(np.abs(w_dev[i] - w_gi)) <= 1e-8 * max(1.0, float(np.abs(w_gi).max())), int(i)
+    assert w_dev.min() >= 0
     grad = w_dev @ P - q
     free = np.ones(len(q), dtype=bool); free[np.intp(anchor)] = False
     scale = np.abs(q).max()

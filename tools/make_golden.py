@@ -489,7 +489,7 @@ def _spectral_parts(docs, K, V, maxV=5000):
     Q_gram = Q.toarray()
     anchor = ref_stm.fastAnchor(Q, K, verbose=False)
     Q_caller = Q.toarray()                       # fastAnchor rescales one row of the caller's matrix
-    beta = ref_stm.recover_l2(Q, anchor, wprob)   # qpsolvers.solve_qp: tools/refshim stand-in (see its docstring)
+    beta = ref_stm.recover_l2(Q, anchor, wprob)   # qpsolvers.solve_qp -> tools/refshim -> the restated Goldfarb-Idnani method
     full = ref_stm.spectral_init(docs, K, V, maxV=maxV, verbose=False)
     return dict(wprob=wprob, keep=keep, Q_gram=Q_gram, anchor=np.asarray(anchor), Q_caller=Q_caller,
                 beta_kept=np.asarray(beta), beta=np.asarray(full))
@@ -507,7 +507,7 @@ def case_spectral_c1():
     save("spectral_c1", K=np.int32(K), V=np.int32(V), corpus=np.asarray("c1_k10"), wprob=r["wprob"], keep=r["keep"],
          anchor=r["anchor"], sample_rows=rows, Q_gram_rows=r["Q_gram"][rows], Q_gram_rowsum=r["Q_gram"].sum(axis=1),
          Q_gram_colsq=(r["Q_gram"] ** 2).sum(axis=0), Q_caller_anchor_rows=r["Q_caller"][np.intp(r["anchor"])],
-         beta_kept=r["beta_kept"], beta=r["beta"], qp_solver=np.asarray("tools/refshim qpsolvers stand-in (scipy nnls)"))
+         beta_kept=r["beta_kept"], beta=r["beta"], qp_solver=np.asarray("Goldfarb-Idnani dual active set (quadprog's algorithm) as restated in oracle/spectral_oracle.py, through tools/refshim/qpsolvers"))
 
 
 def case_spectral_wiki():
@@ -526,7 +526,7 @@ def case_spectral_wiki():
          anchor=r["anchor"], sample_rows=rows, Q_gram_rows=r["Q_gram"][rows], Q_gram_rowsum=r["Q_gram"].sum(axis=1),
          Q_gram_colsq=(r["Q_gram"] ** 2).sum(axis=0), beta_rowsum=r["beta"].sum(axis=1), beta_colsum=r["beta"].sum(axis=0),
          sample_cols=cols, beta_cols=r["beta"][:, cols], beta_kept_anchor_cols=r["beta_kept"][:, np.intp(r["anchor"])],
-         qp_solver=np.asarray("tools/refshim qpsolvers stand-in (scipy nnls)"))
+         qp_solver=np.asarray("Goldfarb-Idnani dual active set (quadprog's algorithm) as restated in oracle/spectral_oracle.py, through tools/refshim/qpsolvers"))
 
 
 def case_k100_v5k():
