@@ -26,6 +26,16 @@ def _corpus(g):
     return PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
 
 
+# ------------------------------------------------------------------ M-step branches beside OLS
+@pytest.mark.parametrize("tag,mode,sp", __import__("_mstep_modes").CONFIGS)
+@pytest.mark.parametrize("resident", [False, True])
+def test_mstep_branches_against_the_reference_on_the_gpu(tag, mode, sp, resident):
+    """mode="ridge" / "lasso" and sigma_prior = 0.5 through the HIP path: host M-step and the resident loop (ridge: the
+    moment-based solve on the reduced statistics; lasso: falls back to the host fit) against the reference's run."""
+    import _mstep_modes
+    _mstep_modes.run(load_golden("mstep_modes"), tag, mode, sp, resident)
+
+
 # ------------------------------------------------------------------ C5: content covariate, device M-step for A > 1
 def test_resident_em_with_content_levels_against_reference():
     """content=True + kappa_interactions=True, A=2: the resident loop runs beta_normalise_topics_kernel (the
@@ -207,6 +217,73 @@ def test_config4_share_invariants_and_oracle_sample(oracle):
     assert np.array_equal(d2["status"][:S], o2["status"]) and np.array_equal(d2["nit"][:S], o2["nit"])
     assert np.max(np.abs(e.get_eta()[:S] - o2["eta"])) <= 1e-7 and np.isfinite(b2)
     e.close()
+
+
+def test_config5_full_size_invariants_oracle_sample_and_mstep(oracle):
+    """BASELINE configs[4] at its full size: 100k documents, V=10k, K=50 with a content covariate (A = 2 levels of beta,
+    stm.py:527-530, 584-588, 741).  Size-independent invariants on everything (per-level column sums of beta_ss = per-level
+    word counts), the oracle on a 1000-document sample, and one full resident iteration's beta against the NumPy
+    statement of the reference's axis-1 normalisation on the device's own beta_ss."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    N, V, K, A = 100_000, 10_000, 50, 2
+    syn = synthetic_corpus(N, V, K, n_words=150, seed=12345)
+    c, n = syn.corpus, K - 1
+    aspect = np.random.default_rng(5).integers(0, A, size=N).astype(np.int32)
+    m = STM(documents=c, dictionary=None, content=True, K=K, X=syn.X, kappa_interactions=True, A=A, beta_index=aspect,
+            max_em_iter=1, sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    beta0 = m.beta.copy()
+    assert beta0.shape == (A, K, c.V)
+    m._em_iteration_resident()
+    e = m._engine
+    eta, theta, beta_ss, bd, diag = e.get_eta(), e.get_theta(), e.get_beta_ss(), e.get_bound_docs(), e.get_diagnostics()
+    doc = np.repeat(np.arange(N), np.diff(c.indptr))
+    for a in range(A):                                     # phi columns sum to the word count, per level
+        sel = aspect[doc] == a
+        wc = np.bincount(c.indices[sel], weights=c.counts[sel], minlength=c.V)
+        assert _rel(beta_ss[a].sum(axis=0), wc) <= 1e-11, a
+    assert abs(beta_ss.sum() - c.counts.sum()) <= 1e-11 * c.counts.sum() and beta_ss.min() >= 0
+    assert np.allclose(theta.sum(axis=1), 1.0, atol=1e-12) and theta.min() > 0
+    assert np.allclose(theta[:, :-1] / theta[:, -1:], np.exp(eta), rtol=1e-12)
+    assert np.isfinite(bd).all() and m.bound == pytest.approx(bd.sum(), rel=1e-12)
+    assert set(np.unique(diag["status"])) <= {0, 2} and set(np.unique(diag["pd_path"])) <= {0, 1, 2}
+    S = 1000
+    sub = c.slice(0, S)
+    z = np.zeros((S, n))
+    o = oracle.estep(sub.indptr, sub.indices, sub.counts, beta0, z, z, m.siginv, float(m.sigmaentropy), aspect=aspect[:S], nthreads=0)
+    for k in ("status", "nit", "pd_path"):
+        assert np.array_equal(diag[k][:S], o[k]), k
+    assert np.max(np.abs(eta[:S] - o["eta"])) <= 1e-7
+    assert np.max(np.abs(bd[:S] - o["bound_doc"]) / np.abs(o["bound_doc"])) <= 1e-8
+    rs = beta_ss.sum(axis=1)[:, None]                      # axis=1 of (A, K, V): over topics (stm.py:741)
+    want = np.divide(beta_ss, rs, out=np.zeros_like(beta_ss), where=rs != 0)
+    assert np.allclose(m.beta, want, rtol=1e-12, atol=0)
+    m.close()
+
+
+def test_late_em_iteration_40_teacher_forced_against_the_oracle(oracle):
+    """Beyond EM iteration ~30 the successful line searches get longer (10 -> 18 evaluations per document): 2000
+    documents of the configs[1] shape driven to EM iteration 40 on the device, then that iteration's E-step from the
+    device's own state through the HIP path and through the oracle -- every scipy status / nit / PD path equal."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(2000, 10_000, 50, n_words=150, seed=77)
+    c = syn.corpus
+    m = STM(documents=c, dictionary=None, content=False, K=50, X=syn.X, kappa_interactions=False, max_em_iter=41,
+            sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    for _ in range(40):
+        m._em_iteration_resident()
+    beta, mu, eta = m.beta.copy(), m.mu.copy(), m.eta.copy()
+    m._em_iteration_resident()                              # EM iteration 40 on the device
+    d = m.solver_diagnostics()
+    siginv, sigent = m.siginv.copy(), float(m.sigmaentropy)
+    o = oracle.estep(c.indptr, c.indices, c.counts, beta, mu, eta, siginv, sigent, nthreads=0)
+    for k in ("status", "nit", "pd_path"):
+        assert np.array_equal(d[k], o[k]), f"{k}: {int(np.sum(d[k] != o[k]))} documents differ"
+    assert d["nit"].mean() > 0.5 and o["nfev"].mean() >= d["nfev"].mean()   # the regime the test is about: steps that move
+    assert np.max(np.abs(m.eta - o["eta"])) <= 1e-7
+    assert m.bound == pytest.approx(o["bound"], rel=1e-10)
+    m.close()
 
 
 # ------------------------------------------------------------------ multi-rank paths

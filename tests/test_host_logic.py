@@ -225,6 +225,15 @@ def test_content_covariate_levels(resident):
     assert np.allclose(m.beta, g["it1_beta_out"], rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("tag,mode,sp", __import__("_mstep_modes").CONFIGS)
+@pytest.mark.parametrize("resident", [False, True])
+def test_mstep_branches_against_the_reference(tag, mode, sp, resident):
+    """mode="ridge" / "lasso" and sigma_prior > 0 (stm.py:678-689, 721-728) against the reference's own two EM iterations;
+    resident=True takes the moment-based ridge solve / shrinkage of the device loop (lasso: the host fallback)."""
+    import _mstep_modes
+    _mstep_modes.run(load_golden("mstep_modes"), tag, mode, sp, resident, engine=OracleEngine())
+
+
 def test_covariance_from_moments_and_its_guard():
     """One all-reduce: (eta - mu)^T (eta - mu) expanded in the reduced moments equals the direct product; when the
     expansion would cancel more than four digits the resident loop takes the exact (second all-reduce) form."""

@@ -170,11 +170,11 @@ def run_em(model, n_iter, keep_beta_ss="full", sample_cols=None):
 
 
 def make_model(docs, dictionary, K, X, model_type="STM", content=False, interactions=False,
-               beta_index=None, A=None, max_em_iter=3, keep_mats=False):
+               beta_index=None, A=None, max_em_iter=3, keep_mats=False, mode="ols", sigma_prior=0):
     m = RecSTM(documents=docs, dictionary=dictionary, content=content, K=K, X=X,
-               kappa_interactions=interactions, max_em_iter=max_em_iter, sigma_prior=0,
+               kappa_interactions=interactions, max_em_iter=max_em_iter, sigma_prior=sigma_prior,
                convergence_threshold=1e-5, init_type="random", model_type=model_type,
-               beta_index=beta_index, A=A)
+               beta_index=beta_index, A=A, mode=mode)
     m._keep_mats = keep_mats
     _install_plus_detector(m)
     return m
@@ -591,7 +591,30 @@ def case_content_k50():
          V=np.int32(len(c.dictionary)), A=np.int32(A), aspect=bidx.astype(np.int32), **out)
 
 
-CASES = dict(toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
+def case_mstep_modes():
+    """The M-step branches beside OLS (stm.py:678-689 mode="ridge" / "lasso", stm.py:721-728 sigma_prior > 0): 300
+    documents of the C1 shape (K = 10, V = 2000) with a THREE-level prevalence covariate (one-hot encoded by update_mu,
+    stm.py:665-667), two EM iterations of the reference per configuration from the same beta0."""
+    K = 10
+    c = _synthetic(K, 2000, 300, 4242)
+    docs = c.documents
+    N = len(docs)
+    X = (np.asarray(c.metadata, dtype=np.float64).reshape(N, -1)[:, 0].astype(np.int64) + np.arange(N) % 2).astype(np.float64)
+    indptr, idx, cnt = docs_to_csr(docs)
+    out = dict(indptr=indptr, indices=idx, counts=cnt, X=X, K=np.int32(K), V=np.int32(len(c.dictionary)))
+    for tag, mode, sp in (("ridge", "ridge", 0), ("lasso", "lasso", 0), ("sp05", "ols", 0.5)):
+        m = make_model(docs, c.dictionary, K, X, max_em_iter=2, mode=mode, sigma_prior=sp)
+        if "beta0" not in out:
+            out["beta0"] = m.beta.copy()
+        assert np.array_equal(out["beta0"], m.beta)
+        r = run_em(m, 2)
+        for k, v in r.items():
+            if k.split("_", 1)[1] in ("bound", "gamma", "mu_out", "sigma_out", "beta_out", "sigma_ss", "status", "nit", "pd_path", "eta"):
+                out[f"{tag}_{k}"] = v
+    save("mstep_modes", **out)
+
+
+CASES = dict(mstep_modes=case_mstep_modes, toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
              wiki_k50=case_wiki_k50, k50_late=case_k50_late, spectral_c1=case_spectral_c1, k100_v5k=case_k100_v5k, content_k50=case_content_k50,
              spectral_wiki=case_spectral_wiki)
