@@ -179,6 +179,9 @@ int stm_spectral_release(stm_handle *h);
  * (any side channel); then every rank calls stm_comm_init. */
 int stm_comm_unique_id(void *out128);
 int stm_comm_init(stm_handle *h, const void *uid128, int rank, int nranks);
+/* what RCCL itself says about the handle's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): bench
+ * provenance for multi-GPU lines.  nranks = 0 when the handle has no communicator. */
+int stm_comm_info(stm_handle *h, int32_t *nranks, int32_t *rank, int32_t *device);
 /* sum over ranks, in place on the device, of the packed buffer
  * [ bound | sigma_ss | moments (as left by stm_mstep_moments) | beta_ss ];
  * the first moments_len doubles of the reduced moment region are copied to `moments` (nullable when 0).

@@ -74,6 +74,7 @@ SIGNATURES = {
     "stm_spectral_release": (C.c_int, [_h]),
     "stm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "stm_comm_init": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
+    "stm_comm_info": (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stm_allreduce_suffstats": (C.c_int, [_h, _dp, _dp, C.c_int64]),
     "stm_allreduce_small": (C.c_int, [_h, _dp, C.c_int64]),
     "stm_last_kernel_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),

@@ -166,11 +166,22 @@ struct stm_handle {
     static constexpr size_t STAGE_BYTES = 1 << 20;
     // pinned regions of the single-synchronisation EM iteration (stm_em_begin / stm_em_finish), so that nothing enqueued
     // there shares a staging area with a transfer still in flight: [0, 1M) read-back, [1M, 1.5M) siginv, [1.5M, 2M) gamma
-    void *stage_em = nullptr;
-    static constexpr size_t EM_BACK = 1 << 20, EM_SIG = 1 << 19, EM_GAM = 1 << 19;
+    // (grow-only: sized from n and p when first needed -- a one-hot X with hundreds of columns reads back megabytes)
+    void *stage_back = nullptr, *stage_sig = nullptr, *stage_gam = nullptr;
+    size_t stage_back_cap = 0, stage_sig_cap = 0, stage_gam_cap = 0;
 };
 
 void stm_spectral_destroy(void *p);
+
+// grow-only pinned host buffer (the stream is drained before an old one is released)
+static int ensure_pinned(stm_handle *h, void **p, size_t *cap, size_t bytes) {
+    if (*p && *cap >= bytes) return STM_OK;
+    if (*p) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipHostFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = std::max<size_t>(bytes, 4096);
+    HIP_TRY(hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return STM_OK;
+}
 
 static int use_device(stm_handle *h) {
     HIP_TRY(hipSetDevice(h->device));
@@ -353,7 +364,6 @@ int stm_create(stm_handle **out, int device_ordinal) {
     for (auto &ev : h->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipEventCreate failed"); }
     if (hipHostMalloc(&h->stage, stm_handle::STAGE_BYTES, hipHostMallocDefault) != hipSuccess) h->stage = nullptr;
-    if (hipHostMalloc(&h->stage_em, stm_handle::EM_BACK + stm_handle::EM_SIG + stm_handle::EM_GAM, hipHostMallocDefault) != hipSuccess) h->stage_em = nullptr;
     *out = h;
     return STM_OK;
 }
@@ -373,7 +383,9 @@ void stm_destroy(stm_handle *h) {
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu); dfree(h->d_prof);
     dfree(h->d_X); dfree(h->d_mom); dfree(h->d_gamma); dfree(h->d_cov); dfree(h->d_pack); dfree(h->d_ascratch); dfree(h->d_small);
     if (h->stage) (void)hipHostFree(h->stage);
-    if (h->stage_em) (void)hipHostFree(h->stage_em);
+    if (h->stage_back) (void)hipHostFree(h->stage_back);
+    if (h->stage_sig) (void)hipHostFree(h->stage_sig);
+    if (h->stage_gam) (void)hipHostFree(h->stage_gam);
     for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -642,8 +654,9 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         sig_bound = std::max(sig_bound, r);
     }
     const size_t KV = (size_t)h->A * K * h->V;
-    if (em_stage && h->stage_em && sizeof(double) * (size_t)n * n <= stm_handle::EM_SIG) {
-        double *st = (double *)((char *)h->stage_em + stm_handle::EM_BACK);
+    if (em_stage) {
+        if (int rc = ensure_pinned(h, &h->stage_sig, &h->stage_sig_cap, sizeof(double) * (size_t)n * n)) return rc;
+        double *st = (double *)h->stage_sig;
         memcpy(st, siginv, sizeof(double) * (size_t)n * n);
         HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     } else if (h->stage && sizeof(double) * (size_t)n * n <= stm_handle::STAGE_BYTES / 2) {   // second half of the staging buffer
@@ -773,7 +786,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
                            h->d_sigma_part, nrep, (int)slab, tiles);
         hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss);
     }
-    hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal);
+    hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal, (const int32_t *)h->d_err);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     return STM_OK;

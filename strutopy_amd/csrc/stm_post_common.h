@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void reduce_sigma_kernel(const double *part, i
     if (ty == 0 && q < nn) out[q] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 
-// bound = np.sum(calculated_bounds) (stm.py:592): one block, fixed tree => deterministic
-__global__ __launch_bounds__(1024) void reduce_bound_kernel(const double *bound, int64_t N, double *out) {
+// bound = np.sum(calculated_bounds) (stm.py:592): one block, fixed tree => deterministic.  out[1] = this rank's device
+// error flag (1.0 per failing rank after the all-reduce of the packed buffer: every rank learns of a failure anywhere in
+// the same collective), out[2] = the flag's value on this rank
+__global__ __launch_bounds__(1024) void reduce_bound_kernel(const double *bound, int64_t N, double *out, const int32_t *err) {
     __shared__ double sh[1024];
     double t = 0.0;
     for (int64_t i = threadIdx.x; i < N; i += 1024) t += bound[i];
@@ -93,7 +95,10 @@ __global__ __launch_bounds__(1024) void reduce_bound_kernel(const double *bound,
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x == 0) {
+        out[0] = sh[0];
+        out[1] = (err && *err) ? 1.0 : 0.0;
+    }
 }
 
 

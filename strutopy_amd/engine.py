@@ -255,6 +255,12 @@ class HipEstepEngine:
         buf = C.create_string_buffer(uid, 128)
         check(self._L.stm_comm_init(self._h, buf, int(rank), int(nranks)))
 
+    def comm_info(self):
+        """RCCL's own view of this handle's communicator: dict(nranks, rank, device); nranks = 0 without one."""
+        n, r, d = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self._L.stm_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        return dict(nranks=n.value, rank=r.value, device=d.value)
+
     def allreduce_suffstats(self, moments):
         """All-reduce the packed [bound | sigma_ss | moments | beta_ss] in place on the device; returns
         (bound, reduced moments).  `moments` is what moments() returned (its values already sit in the buffer)."""

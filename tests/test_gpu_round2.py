@@ -8,6 +8,7 @@ import re
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -34,6 +35,33 @@ def test_mstep_branches_against_the_reference_on_the_gpu(tag, mode, sp, resident
     moment-based solve on the reduced statistics; lasso: falls back to the host fit) against the reference's run."""
     import _mstep_modes
     _mstep_modes.run(load_golden("mstep_modes"), tag, mode, sp, resident)
+
+
+# ------------------------------------------------------------------ wide prevalence design (p ~ 300)
+def test_resident_em_with_three_hundred_covariate_columns():
+    """A prevalence design with 300 columns (what one-hot encoding a category with hundreds of levels gives): the fused
+    iteration reads back 8 + n^2 + (1 + p + n + p^2 + p n) doubles -- far beyond one megabyte -- and the regression
+    moments' per-block partials are p^2 doubles each.  Nothing in stm_em_begin may depend on a fixed-size region: the
+    resident loop must agree with the host M-step (sklearn on the full eta, stm.py:696-723) on the same fit."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(1500, 3000, 10, n_words=60, seed=11)
+    X = np.random.default_rng(2).integers(0, 2, size=(1500, 300)).astype(np.float64)   # 0/1: kept as given (stm.py:662)
+    out = {}
+    for resident in (True, False):
+        m = STM(documents=syn.corpus, dictionary=None, content=False, K=10, X=X, kappa_interactions=False, max_em_iter=2,
+                sigma_prior=0, convergence_threshold=1e-12, init_type="random", mode="ridge")
+        assert m._Xenc.shape[1] == 300
+        m.expectation_maximization(saving=False, resident=resident)
+        out[resident] = (np.array(m.last_bounds), m.beta.copy(), m.sigma.copy(), m.gamma.copy())
+        if resident:
+            assert m.cov_exchanges and len(m.timings) == 2
+        m.close()
+    a, b = out[True], out[False]
+    assert np.allclose(a[0], b[0], rtol=1e-9)
+    assert np.allclose(a[1], b[1], rtol=1e-6, atol=1e-12)
+    assert np.allclose(a[2], b[2], rtol=1e-6, atol=1e-9)
+    assert np.allclose(a[3], b[3], rtol=1e-6, atol=1e-9)
 
 
 # ------------------------------------------------------------------ C5: content covariate, device M-step for A > 1
@@ -409,8 +437,27 @@ def test_bench_launches_its_own_ranks_and_strong_scaling_shards_one_corpus():
     assert np.allclose(weak["strong_scaling"]["elbo_trace"], one["elbo_trace"], rtol=1e-9)
     assert two["config"]["allreduces_per_iteration"] == 1
     assert "roofline" in one and "roofline" not in two
+    # provenance: two ranks on the one GPU of this box are not two GPUs, and the line says so
+    assert one["config"]["devices_distinct"] and not two["config"]["devices_distinct"]
+    assert two["config"]["device_ordinals"] == [0, 0] and two["config"]["rccl_comm_count"] == [0] and two["config"]["allreduce"] == "tcp-host"
     for b in (one, two, weak):
         assert b["value"] == pytest.approx(b["config"]["docs_total"] * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"]), rel=1e-6)
+
+
+def test_explicit_rccl_on_duplicate_devices_fails_cleanly():
+    """`--allreduce rccl` asked for by name must not fall back silently: two ranks on this box's single GPU make RCCL refuse
+    (duplicate device) -- or, if it cannot even be loaded, say so -- and the launcher exits non-zero with the reason,
+    promptly (no rank left hanging in a collective).  The only N > 1 behaviour of RCCL that one GPU can show."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "1000", "--vocab", "1000", "--topics", "10", "--steps", "1",
+           "--warmup", "0", "--cpu-sample", "0", "--gpus", "2", "--allreduce", "rccl"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "STM_RDZV_PORT")}
+    env.update(NCCL_DEBUG="WARN")
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0, r.stdout[-500:]
+    assert time.time() - t < 240
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no bench line from a failed set-up
+    assert re.search(r"ncclCommInitRank|RCCL|rccl|duplicate", r.stderr), r.stderr[-2000:]
 
 
 # ------------------------------------------------------------------ the reference-side stub of INTEGRATION.md, executed
