@@ -138,6 +138,7 @@ struct stm_handle {
     int nw = 1;                  // wavefronts per document in the solver
     int KP = 0;                  // slab row length (doubles)
     int vpl = 1;                 // vector components per lane in the solver (2 for 64 < K <= 128)
+    bool dma = false;            // two-wave solver with LDS-staged row gather (K == KREG = 50 or 64)
     bool direct = false;         // K > 64: rows re-gathered from betaT per pass instead of a per-document slab
     // optional dumps
     double *d_phi = nullptr;
@@ -197,7 +198,9 @@ using SolverFn = void (*)(stm::SolverParams);
 
 // solver instantiations: KREG topics of the register-resident words (0: none), LDS or global slab,
 // one or two wavefronts per document
-static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, bool direct = false) {
+static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, bool direct = false, bool dma = false) {
+    if (dma && kreg == 50) return stm::solver_kernel<1, 50, false, 2, 0, true>;   // K == 50 / 64: rows staged through the LDS
+    if (dma && kreg == 64) return stm::solver_kernel<1, 64, false, 2, 0, true>;
     if (vpl == 2 && direct) return stm::solver_kernel<2, 0, false, 1, 1>;   // 64 < K <= 128, rows re-gathered per pass
     if (vpl == 2) return global_slab ? stm::solver_kernel<2, 0, true> : stm::solver_kernel<2, 0, false>;   // 64 < K <= 128
     if (global_slab) return stm::solver_kernel<1, 0, true>;
@@ -236,6 +239,9 @@ static int plan_solver(stm_handle *h) {
     if (mode == 0) h->nw = 2;
     h->vpl = K > 64 ? 2 : 1;
     if (h->vpl == 2) { h->kreg = 0; h->nw = 1; }   // two vector components per lane: beta_d in LDS / HBM only
+    // rows through the LDS-DMA path: needs K == KREG (packed rows of K doubles are the slab's rows) and 32-bit row offsets
+    h->dma = h->nw == 2 && K == h->kreg && (K == 50 || K == 64) && slab_row(K) == 2 * ((K / 2) | 1) &&
+             ((size_t)h->A * h->V * K + 64) * sizeof(double) < ((size_t)1 << 32) && env_int("STM_SOLVER_DMA", 1) != 0;
     const int vreg = h->kreg > 0 ? 64 * h->nw : 0;
     const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
     const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
@@ -280,7 +286,7 @@ static int plan_solver(stm_handle *h) {
         i = j;
     }
     if (max_dyn > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw, h->vpl, h->direct),
+        hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn);
         if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
@@ -519,8 +525,8 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu);
     dfree(h->d_prof);
     if (env_int("STM_DEBUG_PROF", 0)) {
-        if (int rc = dalloc(&h->d_prof, N * 40)) return rc;
-        HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * N * 40));
+        if (int rc = dalloc(&h->d_prof, N * stm::PROF_SLOTS)) return rc;
+        HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * N * stm::PROF_SLOTS));
     }
     if (env_int("STM_DEBUG_DUMP", 0)) {
         if (int rc = dalloc(&h->d_hess, N * n * n)) return rc;
@@ -676,7 +682,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     }
 
     stm::SolverParams sp{};
-    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = h->KP;
+    sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = h->KP; sp.zrow = (int)((int64_t)h->A * h->V);
     sp.indptr = h->d_indptr; sp.indices = h->d_indices; sp.counts = h->d_counts; sp.aspect = h->d_aspect;
     sp.betaT = h->d_betaT; sp.colsum = h->d_colsum; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag; sp.sig_bound = sig_bound;
     sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
@@ -703,7 +709,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
-            const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl, h->direct);
+            const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma);
             const unsigned bdim = gr.global ? 64u : 64u * (unsigned)h->nw;
             sp.ld = gr.ld;
             sp.lds_doubles = (int)(gr.lds_bytes / sizeof(double));
@@ -827,8 +833,8 @@ int stm_get_phi(stm_handle *h, int64_t doc, double *phi) {
 int stm_debug_get_prof(stm_handle *h, long long *out) {
     NEED_MODEL(h);
     if (!h->d_prof) return fail(STM_ERR_INVALID, "set STM_DEBUG_PROF=1 before stm_set_topics");
-    HIP_TRY(hipMemcpy(out, h->d_prof, sizeof(long long) * (size_t)h->N * 40, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * (size_t)h->N * 40));
+    HIP_TRY(hipMemcpy(out, h->d_prof, sizeof(long long) * (size_t)h->N * stm::PROF_SLOTS, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * (size_t)h->N * stm::PROF_SLOTS));
     return STM_OK;
 }
 

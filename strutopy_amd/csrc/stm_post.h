@@ -68,17 +68,6 @@ __host__ __device__ inline PostLds post_lds_map(int K, int NB) {
     return L;
 }
 
-// explicit waits (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]) as builtins, so that the compiler's
-// own counter bookkeeping sees them
-__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0)
-__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // lgkmcnt(0)
-template <int N> __device__ __forceinline__ void wait_vmem_but() {   // vmcnt(N): all but the N youngest memory operations
-    static_assert(N >= 0 && N < 64, "vmcnt is a six-bit counter");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
-}
-// ties a value to its place among the memory operations (a pure computation is otherwise free to be selected anywhere)
-__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v) :: "memory"); }
-
 // NB 16 x 16 blocks cover the b b^T accumulation on the matrix cores; REM == 1: n = 16 NB + 1 exactly (K = 50:
 // 49 = 3 * 16 + 1), and the one row / column beyond the blocks is carried on the VALU (one double per lane) instead of
 // padding to NB + 1 blocks -- 6 accumulator tiles instead of 10.  The factorisation, the inverse and nu work on
@@ -325,7 +314,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         }
         STM_POST_SYNC();
         sth[lane] = isk ? ths : 0.0;   // inside region 0, behind the matrix: the tiles are done
-        if (DBG && P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
+        if (DBG && P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * PROF_SLOTS + 24 + q] = tq[q];
         if (DBG && P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         relane();
         if (wave_any(sbad || (isk && !(rowc >= 0.0)))) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);   // stm.py:1117
@@ -699,7 +688,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         STM_POST_SYNC();
         if (DBG && P.prof) tp[6] = (long long)__builtin_readcyclecounter();
         relane();
-        if (DBG && P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = ti[2] - ti[1]; P.prof[doc * 40 + 30] = tp[6] - ti[2]; P.prof[doc * 40 + 31] = ti[0] - tp[5]; }
+        if (DBG && P.prof && lane == 0 && !upper) { P.prof[doc * PROF_SLOTS + 28] = ti[1] - ti[0]; P.prof[doc * PROF_SLOTS + 29] = ti[2] - ti[1]; P.prof[doc * PROF_SLOTS + 30] = tp[6] - ti[2]; P.prof[doc * PROF_SLOTS + 31] = ti[0] - tp[5]; }
         // nu = R R^T = X^T X (sigma_ss += nu, stm.py:582), one block column bj of output tiles (bi <= bj) at a time on the
         // matrix cores: nu[i][j] = sum_{l >= 16 bj} X[l][i] X[l][j] (X is lower triangular: rows above block bj add nothing);
         // fragment X[s4 + fq][b*16 + fr], zero above the diagonal.  The workgroup's running sum lives in a slab of its own in
@@ -763,10 +752,10 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 }
             }
         }
-        if (DBG && P.prof && lane == 0 && (P.debug_flags & 32)) for (int q2 = 0; q2 < 4; ++q2) P.prof[doc * 40 + 28 + q2] = tcc[q2];
+        if (DBG && P.prof && lane == 0 && (P.debug_flags & 32)) for (int q2 = 0; q2 < 4; ++q2) P.prof[doc * PROF_SLOTS + 28 + q2] = tcc[q2];
         if (DBG && P.prof && lane == 0) {
             tp[7] = (long long)__builtin_readcyclecounter();
-            for (int q2 = 0; q2 < 7; ++q2) P.prof[doc * 40 + 32 + q2] = tp[q2 + 1] - tp[q2];
+            for (int q2 = 0; q2 < 7; ++q2) P.prof[doc * PROF_SLOTS + 32 + q2] = tp[q2 + 1] - tp[q2];
         }
     }
 }

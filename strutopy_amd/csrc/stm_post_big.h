@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
             if (P.prof) { long long c1 = __builtin_readcyclecounter(); tq[3] += c1 - c0; c0 = c1; }
             my_idx = idx1; my_c = c1n; idx1 = idx2; c1n = c2n;
         }
-        if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * 40 + 24 + q] = tq[q];
+        if (P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * PROF_SLOTS + 24 + q] = tq[q];
         if (P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         if (wave_any(bad)) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);
         const double Ndoc = (double)(long long)wave_sum(csum);
@@ -654,8 +654,8 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         __syncthreads();
         if (P.prof) tp[6] = (long long)__builtin_readcyclecounter();
         relane();
-        if (P.prof && lane == 0 && !upper) { P.prof[doc * 40 + 28] = ti[1] - ti[0]; P.prof[doc * 40 + 29] = tp[6] - ti[1]; }
-        if (P.prof && lane == 0) { P.prof[doc * 40 + 30] = tc[0]; P.prof[doc * 40 + 31] = tc[2]; P.prof[doc * 40 + 23] = tc[1]; }
+        if (P.prof && lane == 0 && !upper) { P.prof[doc * PROF_SLOTS + 28] = ti[1] - ti[0]; P.prof[doc * PROF_SLOTS + 29] = tp[6] - ti[1]; }
+        if (P.prof && lane == 0) { P.prof[doc * PROF_SLOTS + 30] = tc[0]; P.prof[doc * PROF_SLOTS + 31] = tc[2]; P.prof[doc * PROF_SLOTS + 23] = tc[1]; }
         // nu = R R^T = X^T X (sigma_ss += nu, stm.py:582), one block column bj of output tiles (bi <= bj) at a time on the
         // matrix cores: nu[i][j] = sum_{l >= 16 bj} X[l][i] X[l][j]; fragment X[s4 + fq][b*16 + fr], zero above the diagonal
         double *nu_doc = P.nu_out ? P.nu_out + (size_t)doc * n * n : nullptr;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64) void post_big_kernel(PostParams P) {
         }
         if (P.prof && lane == 0) {
             tp[7] = (long long)__builtin_readcyclecounter();
-            for (int q = 0; q < 7; ++q) P.prof[doc * 40 + 32 + q] = tp[q + 1] - tp[q];
+            for (int q = 0; q < 7; ++q) P.prof[doc * PROF_SLOTS + 32 + q] = tp[q + 1] - tp[q];
         }
         __syncthreads();
     }

@@ -38,7 +38,7 @@ struct PostParams {
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
     int MLD;               // leading dimension of the LDS matrix (odd, >= n)
-    long long *prof;       // optional [N][40] (shared with the solver's): [32..39] post-kernel phase cycles
+    long long *prof;       // optional [N][PROF_SLOTS] (shared with the solver's): [32..39] post-kernel phase cycles
     double *rw;            // post_kernel (K <= 64): [nnz] r_dw of stm_betass.h, word-major ...
     const int32_t *wm_slot; // ... at wm_slot[CSR position]
 };

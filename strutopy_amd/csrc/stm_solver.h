@@ -25,6 +25,10 @@
 #include <type_traits>
 #include "stm_wave.h"
 
+#ifndef STM_EVAL_GROUP
+#define STM_EVAL_GROUP 8   // topics per scheduling group of the evaluation's register pass
+#endif
+
 namespace stm {
 
 // LDS hand-off between lanes of ONE wave: the LDS executes a wave's operations in order, so only
@@ -58,10 +62,11 @@ struct SolverParams {
     int32_t *status, *nit, *nfev, *njev;
     int32_t *err_flag;
     int lds_doubles;        // dynamic LDS of this launch, in doubles (debug bit3 poisons it)
+    int zrow;               // DMA form: index of the all-zero row behind the last row of betaT (A * V)
     int debug_flags;        // bit0: skip the BFGS loop (bring-up aid); bit1: no line-search cuts, bit2: no reuse of DCSRCH's first
                             // evaluation by wolfe2 (every evaluation scipy makes is made: A/B check of the shortcuts)
-    long long *prof;        // optional [N][40] shader-clock totals per document: [0] init, [1] evaluations, [2] state machine,
-                            // [3] BFGS update, [8+st] cycles in state st, [24+st] visits of state st
+    long long *prof;        // optional [N][PROF_SLOTS] shader-clock totals per document: [0] init, [1] evaluations, [2] state machine,
+                            // [3] BFGS update, [8+st] cycles in state st (low 40 bits) and visits of it (bits 40..)
 };
 
 enum : int {
@@ -207,7 +212,12 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
 // evaluation) re-gathers the rows from betaT itself, 16 words at a time through one LDS tile: a row is one coalesced
 // run, rows are shared by all documents and stay in the L2 / Infinity Cache, whereas the per-document HBM slab of the
 // GLOBAL_SLAB form (120 KB per document at K = 100) is streamed from HBM once per evaluation.
-template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1, int DIRECT = 0>
+// DMA = true (two-wave form, K == KREG, K / 2 odd or padded to it): the rows of beta_d reach the registers through the LDS.
+// One lane per word, 25 loads of 16 bytes from its own row, touches 64 cache lines per instruction and uses an eighth of
+// each; here a row is one coalesced run moved by the LDS-DMA path into a staging area (the BFGS matrix's, unused until the
+// first update), read back as ds_read_b128 by the lane that owns the word -- and while the rows are there, g0 is summed with
+// lane = topic (two LDS reads, a multiply and an add per word) instead of 50 cross-lane reductions.
+template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1, int DIRECT = 0, bool DMA = false>
 __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
     constexpr int KMAX = 64 * VPL;
     constexpr int VREG = (KREG > 0) ? WAVE * NW : 0;  // words held in registers
@@ -215,6 +225,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     static_assert(KREG % 2 == 0 && KREG <= KMAX, "KREG must be even and <= 64*VPL");
     static_assert(NW == 1 || (NW == 2 && VPL == 1 && KREG > 0 && !GLOBAL_SLAB), "two-wave form: VPL = 1, registers + LDS");
     static_assert(!DIRECT || (VPL == 2 && KREG == 0 && !GLOBAL_SLAB && NW == 1), "direct gather: the K > 64 one-wave form");
+    static_assert(!DMA || (NW == 2 && VPL == 1 && KREG > 0 && !GLOBAL_SLAB && !DIRECT), "LDS-staged gather: the two-wave form");
     constexpr int TWS = 16;   // DIRECT: words per LDS tile
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld] | H[n][n] (NW = 2)
     __shared__ __attribute__((aligned(16))) double se[KMAX + 2];  // exp(eta~ - m), broadcast to every lane
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     enum : int { U_old_fval, U_old_old_fval, U_gnorm, U_phi0, U_old_phi0, U_derphi0, U_Lb, U_Lv, U_prange, U_stx, U_fx, U_gx, U_sty, U_fy, U_gy, U_stmin, U_stmax, U_width, U_width1, U_finit, U_ginit, U_gtest, U_w1_a1, U_w1_f1, U_alpha0, U_alpha1, U_phi_a0, U_phi_a1, U_derphi_a0, U_a_lo, U_a_hi, U_phi_lo, U_phi_hi, U_derphi_lo, U_phi_rec, U_a_rec, U_a_j, U_acc_alpha, U_acc_f, U_alpha, U_fval, U_dval, U_cache_f, U_Ndoc, U_sig_lmax, U_COUNT };
     static_assert(U_COUNT <= 64, "scalar state");                      // [0] request bits (1 f, 2 g, 4 exit, 8 BFGS update (16: from the identity)), [1..2] bad-beta flags
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = NW == 2 ? (int)(threadIdx.x >> 6) : 0;
+    const int wv = NW == 2 ? uni((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to the compiler as such (scalar branches)
     if (threadIdx.x < 64) ss[threadIdx.x] = 0.0;   // (read only after the first workgroup barrier)
     const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
     double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
@@ -294,6 +305,137 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         const double *csv = P.colsum + (size_t)asp * (size_t)P.V;
         if (act) { c0 = P.counts[p0 + wreg]; cs0 = csv[idx_reg]; }
         const double cs_slab = (COOP && lane < NdL) ? csv[idx_slab] : 1.0;
+        long long t_g1 = 0;
+        double csum_all = 0.0;
+        STM_UD(ss, Ndoc);
+        if constexpr (DMA) {
+            // The host selects this form only when K == KREG, KP == 2 * CHP, and every row (and the zero row behind the
+            // last one, P.zrow) is within 4 GiB of P.betaT.
+            constexpr int CH = KREG / 2, CHP = CH | 1, RPI = WAVE / CHP, PITCH = 2 * CHP;   // 16-byte pieces per row (odd: conflict-free b128 reads), rows per fetch, doubles per staged row
+            constexpr int RWX = (((KREG - 1) * (KREG - 1) * 4) / (CHP * 16)) & ~7;          // rows in one wave's half of the BFGS matrix area, whole octets
+            constexpr int RW = RWX < WAVE ? RWX : WAVE;
+            static_assert(RW >= 8 && RW % RPI == 0 && WAVE % 8 == 0, "staging area");
+            constexpr unsigned long long FULL = RPI * CHP >= 64 ? ~0ull : ((1ull << (RPI * CHP)) - 1ull);
+            const unsigned K8 = 8u * (unsigned)K;
+            const int rr = lane / CHP, cc = lane - rr * CHP;
+            const unsigned coff = 16u * (unsigned)(cc < CH ? cc : CH - 1);                 // (the padding piece repeats the row's last one)
+            const unsigned arow = (unsigned)asp * (unsigned)P.V;
+            // byte offset of the row of this lane's register word / slab word; words the document does not have: the zero row
+            const unsigned off_reg = (act ? arow + (unsigned)idx_reg : (unsigned)P.zrow) * K8;
+            const unsigned off_slab = (lane < NdL ? arow + (unsigned)idx_slab : (unsigned)P.zrow) * K8;
+            double *stg = Hs + wv * (RW * PITCH);
+            const unsigned stg_lds = lds_addr(stg), slab_lds = lds_addr(slab);
+            // the rows of the words held by lanes first .. first + RPI - 1 of `offv`, packed, to LDS address dst
+            auto fetch = [&](unsigned offv, int first, unsigned dst, unsigned long long mask) __attribute__((always_inline)) {
+                const unsigned o = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (first + rr), (int)offv) + coff;
+                lds_dma16(P.betaT, o, dst, mask);
+            };
+            // c / colsum of this wave's register words (sv / sw are free until the first evaluation); the choice is made
+            // opaque, or every read through it becomes two reads and a select
+            __attribute__((address_space(3))) double *wq = (__attribute__((address_space(3))) double *)(wv == 0 ? sv : sw);
+            asm volatile("" : "+v"(wq));
+            const int nsl = NdL < WAVE ? NdL : WAVE;  // slab words that pair up with this wave's register words in the sums
+            const int kk = lane < K ? lane : K - 1;   // lane = topic
+            double Qc = 0.0, Oc = 0.0, Sc = 0.0, Pc = 0.0, T = 0.0;   // the reduction tree's pending sums of 4 / 8 / 16 / 32 words
+#pragma unroll
+            for (int ph = 0; ph * RW < WAVE; ++ph) {
+                const int r0 = ph * RW, nr = (WAVE - r0 < RW) ? WAVE - r0 : RW;
+#pragma unroll
+                for (int i = 0; i < nr; i += RPI) fetch(off_reg, r0 + i, stg_lds + (unsigned)(i * PITCH * 8), FULL);
+                if (ph == 0) {
+                    // the slab rows straight to their place (lane-packed rows: pitch KP = PITCH)
+                    for (int j = 0; j < nsl; j += RPI) {
+                        const int rows = nsl - j < RPI ? nsl - j : RPI;
+                        fetch(off_slab, j, slab_lds + (unsigned)(j * PITCH * 8), rows == RPI ? FULL : ((1ull << (rows * CHP)) - 1ull));
+                    }
+                    for (int v0 = WAVE; v0 < NdL; v0 += WAVE) {   // documents beyond 192 words (rare)
+                        const int cnt = NdL - v0 < WAVE ? NdL - v0 : WAVE;
+                        const unsigned o2 = (lane < cnt ? arow + (unsigned)P.indices[p0 + VREG + v0 + lane] : (unsigned)P.zrow) * K8;
+                        for (int j = 0; j < cnt; j += RPI) {
+                            const int rows = cnt - j < RPI ? cnt - j : RPI;
+                            fetch(o2, j, slab_lds + (unsigned)((v0 + j) * PITCH * 8), rows == RPI ? FULL : ((1ull << (rows * CHP)) - 1ull));
+                        }
+                    }
+                }
+                wait_vmem();
+                STM_WAVE_SYNC();
+                if (ph == 0) {
+                    if (act) { w0 = c0 / cs0; csum += c0; }
+                    wq[lane] = w0;
+                    if (wv == 1) svb[lane] = (lane < NdL) ? cnt_slab / cs_slab : 0.0;
+                    for (int vv = lane; vv < NdL; vv += WAVE) {
+                        const double c = vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
+                        const double colsum = vv < WAVE ? cs_slab : csv[P.indices[p0 + VREG + vv]];
+                        crow[vv] = c;
+                        wrow[vv] = c / colsum;
+                        csum += c;
+                    }
+                    STM_WAVE_SYNC();
+                }
+                if (lane >= r0 && lane < r0 + nr) {
+                    const double2 *row2 = reinterpret_cast<const double2 *>(stg + (lane - r0) * PITCH);
+#pragma unroll
+                    for (int k = 0; k < KR; k += 2) {
+                        const double2 t = row2[k >> 1];
+                        breg[k] = t.x;
+                        breg[k + 1] = t.y;
+                    }
+                }
+                // g0 = beta_d @ (c / colsum) (stm.py:954), lane = topic: the leaves and the balanced tree of wave_sum() over the
+                // wave's 64 words -- the same additions in the same pairing as the cross-lane form, so the same bits.  Four
+                // words at a time (the scheduler would otherwise hoist a whole phase's LDS reads above beta_d's registers).
+#pragma unroll
+                for (int j0 = 0; j0 < nr; j0 += 4) {
+                    const int wi0 = r0 + j0, qi = wi0 >> 2;
+                    double v[4];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (wv == 1 && wi0 < NdL) {   // uniform: these words pair up with slab words wi0 .. (beyond the last: weight 0)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sr = wi0 + u < nsl ? wi0 + u : nsl - 1;
+                            const double sl = slab[(size_t)sr * KP + kk];
+                            bad |= !(sl >= 0.0);
+                            v[u] = stg[(j0 + u) * PITCH + kk] * wq[wi0 + u];
+                            v[u] = v[u] + sl * svb[wi0 + u];
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = stg[(j0 + u) * PITCH + kk] * wq[wi0 + u];
+                    }
+                    const double Q = (v[0] + v[1]) + (v[2] + v[3]);
+                    if ((qi & 1) == 0) Qc = Q;
+                    else {
+                        const double O = Qc + Q;
+                        if ((qi & 2) == 0) Oc = O;
+                        else {
+                            const double S = Oc + O;
+                            if ((qi & 4) == 0) Sc = S;
+                            else {
+                                const double Pn = Sc + S;
+                                if ((qi & 8) == 0) Pc = Pn; else T = Pc + Pn;
+                            }
+                        }
+                    }
+                }
+                wait_lds();   // every read of the staging area has returned before the next rows are fetched into it
+                STM_WAVE_SYNC();
+            }
+#pragma unroll
+            for (int k = 0; k < KR; ++k) bad |= !(breg[k] >= 0.0);
+            g0[0] = (lane < n) ? T : 0.0;
+            if (NdL > WAVE) {   // slab words beyond the first 64 (uniform; rare)
+                for (int vv = WAVE; vv < NdL; ++vv) bad |= !(slab[(size_t)vv * KP + kk] >= 0.0);
+                for (int k = 0; k < n; ++k) {
+                    double t = 0.0;
+                    for (int vv = lane + WAVE; vv < NdL; vv += WAVE) t += slab[SI(vv, k)] * wrow[vv];
+                    t = wave_sum(t);
+                    if (lane == k) g0[0] += t;
+                }
+            }
+            t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            if (P.prof && wv == 1 && lane == 0) P.prof[doc * PROF_SLOTS + 7] = t_g1 - t_begin;
+        }
+        if constexpr (!DMA) {
         if (KREG > 0) {
             // unconditional loads of KREG doubles from the row start (the buffer is padded; rows are 16-byte aligned for even K),
             // zeros beyond K by selection: no branch per topic
@@ -395,12 +537,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             wrow[vv] = c / colsum;
             csum += c;
         }
-        const long long t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-        if (P.prof && NW == 2 && wv == 1 && lane == 0) P.prof[doc * 40 + 7] = t_g1 - t_begin;   // wave 1: register rows + slab
+        t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+        if (P.prof && NW == 2 && wv == 1 && lane == 0) P.prof[doc * PROF_SLOTS + 7] = t_g1 - t_begin;   // wave 1: register rows + slab
+        }   // !DMA
         // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
         if (wv == 0)
             for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
-        double csum_all = wave_sum(csum);
+        csum_all = wave_sum(csum);
         bool bad_all = wave_any(bad);
         if (NW == 2) {
             if (lane == 0) { xch_res[4 + wv] = csum_all; xch_cmd[1 + wv] = bad_all ? 1 : 0; }
@@ -414,9 +557,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
             return;
         }
-        STM_UD(ss, Ndoc);
         Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
-        if (COOP && NdL > 0) {
+        if (!DMA && COOP && NdL > 0) {
             // lane = word again for the column sums of the slab rows (same order of additions as the per-lane gather loop);
             // only this wave reads crow / wrow before the next hand-off
             STM_WAVE_SYNC();
@@ -507,8 +649,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             for (int r = 0; r < VPL; ++r)
                 if (k == lane + WAVE * r) g0[r] = t;
         };
-        if constexpr (DIRECT) {
-            // done above, tile by tile
+        if constexpr (DIRECT || DMA) {
+            // done above (DIRECT: tile by tile; DMA: from the staged rows)
         } else if (KREG > 0 && VPL == 1) {
             // wave_sum()'s additions in wave_sum()'s order, but the four row totals of every topic are combined for all
             // topics at once: after the intra-row steps lane (row r, position c) keeps the row-r total of topic 16 q + c
@@ -582,7 +724,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         }
 
         const long long t_g3 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-        if (P.prof && lane == 0 && wv == 0) { P.prof[doc * 40 + 4] = t_g1 - t_begin; P.prof[doc * 40 + 5] = t_g2 - t_g1; P.prof[doc * 40 + 6] = t_g3 - t_g2; }
+        if (P.prof && lane == 0 && wv == 0) { P.prof[doc * PROF_SLOTS + 4] = t_g1 - t_begin; P.prof[doc * PROF_SLOTS + 5] = t_g2 - t_g1; P.prof[doc * PROF_SLOTS + 6] = t_g3 - t_g2; }
         long long t_init = 0, t_eval = 0, t_sm = 0, t_upd = 0;
         int nfev = 0, njev = 0;
         double *svx = (NW == 2 && wv == 1) ? svb : sv;  // this wave's private broadcast vector
@@ -628,7 +770,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 for (int k = 0; k < KR; k += 2) {
                     // bound the number of se values in flight (the scheduler would otherwise
                     // hoist all KREG broadcast reads and spill beta_d out of the VGPRs)
-                    if (k % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+                    if (k % STM_EVAL_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
                     const double2 e = se2[k / 2];
                     s0 = fma(e.x, breg[k], s0);
                     s1 = fma(e.y, breg[k + 1], s1);
@@ -852,20 +994,39 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         auto eval_split = [&](bool do_f, bool do_g, double &f_out) __attribute__((always_inline)) {
             double m = 0.0, ssum = 0.0, e_lane = 0.0;
             int icnt = 1;
+            // -DSTM_EVAL_PROF: where one evaluation's cycles go on wave 0 (profile slots 40..44, accumulated in memory).  Not in
+            // the shipped build: the clock reads cost ten spilled SGPRs around every evaluation.
+#ifdef STM_EVAL_PROF
+            long long tc = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            auto lap = [&](int slot) __attribute__((always_inline)) {
+                if (P.prof) {
+                    const long long now = (long long)__builtin_readcyclecounter();
+                    if (lane == 0) P.prof[doc * PROF_SLOTS + slot] += now - tc;
+                    tc = now;
+                }
+            };
+#else
+            auto lap = [](int) __attribute__((always_inline)) {};
+#endif
             if (lane < n) xch_xt[lane] = xt[0];
             if (lane == 0) xch_cmd[0] = (do_f ? 1 : 0) | (do_g ? 2 : 0);
             __syncthreads();   // (0) wave 1 starts on df and the quadratic form ...
-            if (do_f) {        // ... while this wave takes max / exp(eta~ - m)
+            lap(40);
+            double lse = 0.0, part = 0.0;
+            if (do_f) {        // ... while this wave takes max / exp(eta~ - m) and the log-sum-exp
                 head_F(m, icnt, ssum, e_lane);
                 if (lane == 0) xch_res[2] = m;
-            }
-            __syncthreads();   // (1)
-            double lse = 0.0, part = 0.0;
-            if (do_f) {
                 lse = lse_F(m, icnt, ssum);
+            }
+            lap(41);
+            __syncthreads();   // (1)
+            lap(42);
+            if (do_f) {
                 part = wave_sum(data_F(m, e_lane, 0));   // words 0..63 (wave 1 owns the slab)
             }
+            lap(43);
             __syncthreads();   // (2)
+            lap(44);
             if (do_f) {
                 const double part_all = part + uni(xch_res[0]);
                 const double q = uni(xch_res[1]);
@@ -1373,7 +1534,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 const long long tq2 = (long long)__builtin_readcyclecounter();
                 t_eval += tq1 - tq0;
                 if (was_upd) t_upd += tq2 - tq1; else t_sm += tq2 - tq1;
-                if (lane == 0) { P.prof[doc * 40 + 8 + st_in] += tq2 - tq1; P.prof[doc * 40 + 24 + st_in] += 1; }
+                if (lane == 0) P.prof[doc * PROF_SLOTS + 8 + st_in] += (tq2 - tq1) + (1LL << 40);   // cycles in the low 40 bits, visits above (slots 24.. are the post kernels')
             }
         }
         if (NW == 2) {  // release the evaluation server
@@ -1396,7 +1557,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         }
         // uniform stores (every lane writes the same word)
         if (P.prof && lane == 0) {
-            P.prof[doc * 40 + 0] = t_init; P.prof[doc * 40 + 1] = t_eval; P.prof[doc * 40 + 2] = t_sm; P.prof[doc * 40 + 3] = t_upd;
+            P.prof[doc * PROF_SLOTS + 0] = t_init; P.prof[doc * PROF_SLOTS + 1] = t_eval; P.prof[doc * PROF_SLOTS + 2] = t_sm; P.prof[doc * PROF_SLOTS + 3] = t_upd;
         }
         if (P.status) P.status[doc] = status;
         if (P.nit) P.nit[doc] = k;

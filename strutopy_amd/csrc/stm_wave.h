@@ -4,10 +4,14 @@
 // component per lane (VPL components per lane when n > 64); scalars of the line search
 // are wave-uniform (struct ud: LDS slots), so the solver's control flow compiles to scalar branches.
 #pragma once
+#include <cstdint>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace stm {
+
+constexpr int PROF_SLOTS = 48;   // shader-clock counters per document of the debug profile (STM_DEBUG_PROF; stm_debug_get_prof)
+
 
 constexpr int WAVE = 64;
 
@@ -183,6 +187,32 @@ __device__ __forceinline__ double log1p_pos(double x) {
     const double c = x - (u - 1.0);
     const double l = log_pos(u);
     return (u == INFINITY) ? l : l + c * __builtin_amdgcn_rcp(u);
+}
+
+// explicit waits (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]) as builtins, so that the compiler's
+// own counter bookkeeping sees them
+__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0)
+__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // lgkmcnt(0)
+template <int N> __device__ __forceinline__ void wait_vmem_but() {   // vmcnt(N): all but the N youngest memory operations
+    static_assert(N >= 0 && N < 64, "vmcnt is a six-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+// ties a value to its place among the memory operations (a pure computation is otherwise free to be selected anywhere)
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v) :: "memory"); }
+
+// LDS byte address of a pointer into the workgroup's LDS (what M0 carries for the LDS-DMA loads)
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// global_load_lds_dwordx4: every enabled lane (`mask`) moves 16 bytes from base + off to LDS byte address dst + 16 * lane.
+// Hand-written, so that the compiler does not take it for a memory operation its LDS reads must wait for -- the caller
+// waits (wait_vmem) before it reads what was fetched.  M0 and exec are saved and restored: the compiler owns both.
+__device__ __forceinline__ void lds_dma16(const void *base, unsigned off, unsigned dst, unsigned long long mask) {
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %5\n\t"
+                 "global_load_lds_dwordx4 %2, %4\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(off), "s"(dst), "s"(base), "s"(mask) : "memory");
 }
 
 }  // namespace stm

@@ -15,7 +15,7 @@ m = STM(documents=syn.corpus, dictionary=None, content=False, K=KK, X=syn.X, kap
         sigma_prior=0, convergence_threshold=1e-9, init_type="random")
 for it in range(ITS):
     m._em_iteration_resident()
-    out = np.zeros((m.N, 40), dtype=np.int64)
+    out = np.zeros((m.N, 48), dtype=np.int64)
     _lib.check(_lib.lib().stm_debug_get_prof(m._engine._h, out.ctypes.data_as(C.POINTER(C.c_longlong))))
     if it < FIRST:
         continue
@@ -26,6 +26,7 @@ for it in range(ITS):
           f" kernel {m.timings[-1]['kernels']}")
     if "pd_path" in d: print("   pd_path counts", np.bincount(d["pd_path"], minlength=3))
     print("   solver set-up cycles/doc (wave 0): gather %.0f, word-count exchange %.0f, lane vectors + g0 %.0f; wave 1 gather incl. slab %.0f" % tuple(out[:, 4:8].mean(0)))
+    print("   one evaluation on wave 0, cycles/doc: post + barrier 0 %.0f, max/exp %.0f, barrier 1 %.0f, lse + data term %.0f, barrier 2 %.0f" % tuple(out[:, 40:45].mean(0)))
     names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
              "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "ZOOM_NEXT", "ACCEPT", "ACCEPT2", "FINISH"]
     pn = ["prologue", "word tiles", "H assembly", "Cholesky ladder", "bound", "inverse", "nu"]
@@ -36,6 +37,6 @@ for it in range(ITS):
     if KK > 64:   # post_big_kernel reuses the last two slots (and slot 23) for its Cholesky
         print("   post_big Cholesky cycles/doc: block column updates %.0f, panel loads %.0f, panels %.0f" % (out[:, 30].mean(), out[:, 23].mean(), out[:, 31].mean()))
     for i, nm in enumerate(names):
-        c, v = out[:, 8 + i].mean(), out[:, 24 + i].mean()
+        c, v = (out[:, 8 + i] & ((1 << 40) - 1)).mean(), (out[:, 8 + i] >> 40).mean()
         if v > 0:
             print(f"      {nm:12s} visits/doc {v:6.2f}  cycles/visit {c / v:8.0f}  cycles/doc {c:9.0f}")
