@@ -138,6 +138,8 @@ struct stm_handle {
     int nw = 1;                  // wavefronts per document in the solver
     int KP = 0;                  // slab row length (doubles)
     int vpl = 1;                 // vector components per lane in the solver (2 for 64 < K <= 128)
+    double *d_red = nullptr;     // first-stage sums of the two-stage reductions + the bound's per-block sums
+    size_t red_len = 0;
     bool dma = false;            // two-wave solver with LDS-staged row gather (K == KREG = 50 or 64)
     bool direct = false;         // K > 64: rows re-gathered from betaT per pass instead of a per-document slab
     // optional dumps
@@ -186,6 +188,22 @@ static int ensure_pinned(stm_handle *h, void **p, size_t *cap, size_t bytes) {
 
 static int use_device(stm_handle *h) {
     HIP_TRY(hipSetDevice(h->device));
+    return STM_OK;
+}
+
+// out[nn] = sum of the nblocks copies part[b][nn], fixed order; many copies: in two stages of RED_Y block rows
+constexpr int RED_Y = 32, BOUND_BLOCKS = 128;
+static int reduce_copies(stm_handle *h, const double *part, int nblocks, int nn, double *out) {
+    const unsigned gx = (unsigned)((nn + 63) / 64);
+    if (nblocks < 4 * RED_Y) {
+        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3(gx), dim3(256), 0, h->stream, part, nblocks, nn, out, nblocks);
+    } else {
+        if (int rc = ensure(&h->d_red, &h->red_len, (size_t)RED_Y * nn + BOUND_BLOCKS)) return rc;
+        const int chunk = (nblocks + RED_Y - 1) / RED_Y;
+        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3(gx, RED_Y), dim3(256), 0, h->stream, part, nblocks, nn, h->d_red + BOUND_BLOCKS, chunk);
+        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3(gx), dim3(256), 0, h->stream, (const double *)(h->d_red + BOUND_BLOCKS), RED_Y, nn, out, RED_Y);
+    }
+    HIP_TRY(hipGetLastError());
     return STM_OK;
 }
 
@@ -382,7 +400,7 @@ void stm_destroy(stm_handle *h) {
     stm_spectral_destroy(h->spectral);
     dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
     dfree(h->d_wm_doc); dfree(h->d_wm_pos); dfree(h->d_rw); dfree(h->d_cptr); dfree(h->d_bss_part);
-    dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_colsum); dfree(h->d_eta); dfree(h->d_mu);
+    dfree(h->d_red); dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_colsum); dfree(h->d_eta); dfree(h->d_mu);
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
     dfree(h->d_status); dfree(h->d_nit); dfree(h->d_nfev); dfree(h->d_njev); dfree(h->d_pd);
     dfree(h->d_counters); dfree(h->d_err); dfree(h->d_slab_beta); dfree(h->d_slab_H); dfree(h->d_phi);
@@ -783,16 +801,16 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     if (slab == (size_t)n * n) {
-        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((n * n + 63) / 64), dim3(256), 0, h->stream,
-                           h->d_sigma_part, nrep, n * n, h->d_sigma_ss);
+        if (int rc = reduce_copies(h, h->d_sigma_part, nrep, n * n, h->d_sigma_ss)) return rc;
         hipLaunchKernelGGL(stm::mirror_blocks_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, h->d_sigma_ss, n);
     } else {   // post_kernel's slabs: summed in their tile layout, then laid out as the matrix
         double *tiles = h->d_sigma_part + (size_t)nrep * slab;
-        hipLaunchKernelGGL(stm::reduce_sigma_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, h->stream,
-                           h->d_sigma_part, nrep, (int)slab, tiles);
+        if (int rc = reduce_copies(h, h->d_sigma_part, nrep, (int)slab, tiles)) return rc;
         hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss);
     }
-    hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_bound, h->N, h->d_scal, (const int32_t *)h->d_err);
+    if (int rc = ensure(&h->d_red, &h->red_len, (size_t)BOUND_BLOCKS)) return rc;   // (first BOUND_BLOCKS slots: the bound's block sums)
+    hipLaunchKernelGGL(stm::bound_partial_kernel, dim3(BOUND_BLOCKS), dim3(256), 0, h->stream, (const double *)h->d_bound, h->N, h->d_red);
+    hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, (const double *)h->d_red, (int64_t)BOUND_BLOCKS, h->d_scal, (const int32_t *)h->d_err);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     return STM_OK;

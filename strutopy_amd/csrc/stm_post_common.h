@@ -60,13 +60,17 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 
 // out = sum over the replicated / per-block partial copies, in a fixed order: 64 slots per block, the copies
-// split over four 64-thread groups, four independent partial sums per thread, then a fixed combine
-__global__ __launch_bounds__(256) void reduce_sigma_kernel(const double *part, int nblocks, int nn, double *out) {
+// split over four 64-thread groups, four independent partial sums per thread, then a fixed combine.
+// gridDim.y > 1: block row y sums the copies [y * chunk, (y + 1) * chunk) into out + y * nn (the first of two stages:
+// one thread walking thousands of copies is a chain of dependent memory round trips)
+__global__ __launch_bounds__(256) void reduce_sigma_kernel(const double *part, int nblocks, int nn, double *out, int chunk) {
     __shared__ double sh[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + tx;
-    const int per = (nblocks + 3) >> 2;
-    const int b0 = ty * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    const int lo = blockIdx.y * chunk, hi = lo + chunk < nblocks ? lo + chunk : nblocks;
+    const int cnt = hi > lo ? hi - lo : 0;
+    const int per = (cnt + 3) >> 2;
+    const int b0 = lo + ty * per, b1 = b0 + per < hi ? b0 + per : hi;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     if (q < nn) {
         int b = b0;
@@ -79,7 +83,23 @@ __global__ __launch_bounds__(256) void reduce_sigma_kernel(const double *part, i
     }
     sh[ty][tx] = (t0 + t1) + (t2 + t3);
     __syncthreads();
-    if (ty == 0 && q < nn) out[q] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    if (ty == 0 && q < nn) out[(size_t)blockIdx.y * nn + q] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+}
+
+// per-block sums of contiguous chunks of the per-document bounds (first stage of reduce_bound_kernel)
+__global__ __launch_bounds__(256) void bound_partial_kernel(const double *bound, int64_t N, double *part) {
+    __shared__ double sh[256];
+    const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t d0 = (int64_t)blockIdx.x * chunk, d1 = d0 + chunk < N ? d0 + chunk : N;
+    double t = 0.0;
+    for (int64_t i = d0 + threadIdx.x; i < d1; i += 256) t += bound[i];
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 
 // bound = np.sum(calculated_bounds) (stm.py:592): one block, fixed tree => deterministic.  out[1] = this rank's device
