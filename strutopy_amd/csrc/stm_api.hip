@@ -691,7 +691,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
+    // (post_big_kernel adds phi atomically; the K <= 64 word-major pass writes every cell of beta_ss)
+    if (K > 64 || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
     // last document's phi is what the reference leaves in self.phi (stm.py:1116)
     h->phi_doc = h->N - 1;
     if (h->N > 0) {

@@ -3,7 +3,8 @@
 
 The post kernel is launched exactly once per EM iteration, the solver once per LDS-occupancy class of the
 longest-first document order (several dispatches per iteration): dispatches are walked in order and an
-iteration ends with its post-kernel dispatch.  The first W iterations are the warm-up (EM iterations
+iteration starts with the first solver dispatch behind a post-kernel dispatch (the beta_ss pass that follows the
+K <= 64 post kernel belongs to the iteration of that post kernel).  The first W iterations are the warm-up (EM iterations
 0..W-1 of a fit that is then reset), the next K the timed EM iterations 0..K-1.
 
   by_iteration.py trace  <kernel_trace.csv> W K          -> per-iteration kernel durations (ms), grouped 0 / 1-3 / 4 / 5+
@@ -21,6 +22,8 @@ def kname(r):
         return "solver"
     if "post_big_kernel" in n or "post_kernel" in n:
         return "post"
+    if "beta_ss_part_kernel" in n or "beta_ss_reduce_kernel" in n:
+        return "betass"      # the word-major beta_ss pass behind the K <= 64 post kernel (round 3)
     return None
 
 
@@ -30,29 +33,32 @@ def group_of(it):
 
 if mode == "trace":
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    its, cur = [], collections.defaultdict(float)
+    its, cur, seen_post = [], collections.defaultdict(float), False
     for r in rows:
         k = kname(r)
         if not k:
             continue
+        if k == "solver" and seen_post:
+            its.append(cur); cur, seen_post = collections.defaultdict(float), False
         cur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         cur[k + "_n"] += 1
         if k == "post":
-            its.append(dict(cur)); cur = collections.defaultdict(float)
+            seen_post = True
+    its.append(cur)
     timed = its[W:W + K]
     print(f"{len(its)} EM iterations in the trace ({W} warm-up, {len(timed)} timed); kernel time per EM iteration, ms")
-    print(f"{'EM it':>6s} {'solver':>9s} {'(launches)':>10s} {'post':>9s}")
+    print(f"{'EM it':>6s} {'solver':>9s} {'(launches)':>10s} {'post':>9s} {'beta_ss':>9s}")
     for i, t in enumerate(timed):
-        print(f"{i:6d} {t['solver']:9.3f} {int(t['solver_n']):10d} {t['post']:9.3f}")
+        print(f"{i:6d} {t['solver']:9.3f} {int(t['solver_n']):10d} {t['post']:9.3f} {t['betass']:9.3f}")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for i, t in enumerate(timed):
-        for k in ("solver", "post"):
+        for k in ("solver", "post", "betass"):
             agg[group_of(i)][k].append(t[k])
     print("groups (mean ms per EM iteration):")
     for g in ("it0", "it1-3", "it4", "it5+"):
         if g in agg:
-            print(f"  {g:6s} solver {sum(agg[g]['solver']) / len(agg[g]['solver']):8.3f}   post {sum(agg[g]['post']) / len(agg[g]['post']):8.3f}   ({len(agg[g]['post'])} iterations)")
-    for k in ("solver", "post"):
+            print(f"  {g:6s} solver {sum(agg[g]['solver']) / len(agg[g]['solver']):8.3f}   post {sum(agg[g]['post']) / len(agg[g]['post']):8.3f}   beta_ss {sum(agg[g]['betass']) / len(agg[g]['betass']):8.3f}   ({len(agg[g]['post'])} iterations)")
+    for k in ("solver", "post", "betass"):
         v = [t[k] for t in timed]
         print(f"  all    {k} mean {sum(v) / len(v):.3f} ms over the {len(v)} timed iterations")
 else:
@@ -64,16 +70,18 @@ else:
         if not k:
             continue
         by_disp.setdefault(int(r["Dispatch_Id"]), (k, {}))[1][r["Counter_Name"]] = by_disp.get(int(r["Dispatch_Id"]), (k, {}))[1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    it, agg, nits = 0, collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    it, agg, nits, seen_post = 0, collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter(), False
     for d, (k, cs) in by_disp.items():
-        if it >= W:
+        if k == "solver" and seen_post:
+            it, seen_post = it + 1, False
+        if k == "post":
+            seen_post = True
+        if W <= it < W + K:
             g = group_of(it - W)
             for c, v in cs.items():
                 agg[(g, k)][c] += v
             if k == "post":
                 nits[g] += 1
-        if k == "post":
-            it += 1
     for (g, k), cs in sorted(agg.items()):
         print(f"{g} {k}  (summed over {nits[g]} EM iterations; divide for per-iteration figures)")
         for c, v in sorted(cs.items()):
