@@ -5,26 +5,31 @@
 //   decompose_hessian (1031-1050), lower_bound (1068-1101), optimize_nu (1052-1066),
 //   update_z (1103-1118) and the sigma_ss / beta_ss accumulation (582-588).
 //
-// One wavefront per workgroup, PERSISTENT over a strided set of documents, and built to be RESIDENT TWELVE TO A CU
-// (three waves per SIMD: <= 168 registers, 10.7 KB of LDS at K = 50) -- every phase of a document is a chain of
-// dependent instructions, and what hides one wave's latencies is the other waves of its SIMD.
+// One wavefront per workgroup, PERSISTENT over a strided set of documents, and built to be resident ELEVEN to a CU
+// (three waves per SIMD by registers: 156 VGPRs, no scratch; 14 KB of LDS at K = 50 with the double-buffered word tile) --
+// every phase of a document is a chain of dependent instructions, and what hides one wave's latencies is the other waves
+// of its SIMD.  The kernel issues NO atomics.
 //
-// Words are processed in tiles of 16, word-major in LDS (T[word][topic], exactly the layout of betaT's rows):
+// Words are processed in tiles of 16, word-major in LDS (T[word][topic], exactly the layout of betaT's rows), two tile
+// buffers:
 //   0. fetch    the tile's 16 beta rows go from betaT[A][V][K] STRAIGHT INTO LDS (global_load_lds_dwordx4: lane l of
-//               instruction q moves 16-byte chunk 64 q + l of the tile) -- no staging registers, no transposition, and the
-//               fetch of tile t+1 is issued as soon as the matrix cores have read tile t
+//               instruction q moves 16-byte chunk 64 q + l of the tile) -- no staging registers, no transposition; the
+//               fetch of tile t+1 is issued at the top of tile t's round, the word ids / counts / slots of tile t+2 with it
 //   1. sums     lane = (word, quarter of the topics): colsum S_w and theta.(beta*exp(eta)) per word; the four quarters sit
-//               in one DPP quad; log / sqrt / division once per word
-//   2. scatter  lane = topic: phi = a*c/S is atomically added to beta_ssT[word][:] -- one coalesced 8K-byte run per word
-//               (fp64 hardware atomics) -- and T is overwritten with b = a*sqrt(c)/S
+//               in one DPP quad; log / sqrt / division once per word.  r_dw = (sum_k exp(eta~)_k) c / S_w -- all that
+//               beta_ss needs of this (document, word), see stm_betass.h -- is stored to the entry's word-major slot
+//   2. scatter  lane = topic: T is overwritten with b = a*sqrt(c)/S (phi itself is only formed for the one document whose
+//               phi the reference keeps, stm.py:1116)
 //   3. b b^T    fp64 MFMA (v_mfma_f64_16x16x4_f64): the K x K contraction, upper block triangle only, accumulated in
 //               registers over all tiles of the document
 // The (K-1)^2 matrix then lives in LDS as its LOWER TRIANGLE ONLY, row-packed (rows padded to an even length: 16-byte
-// rows), aliasing the tile: the blocked Cholesky (block-column updates on the matrix cores, 16-column panels factorised
-// right-looking in registers with v_readlane broadcasts) overwrites it with L, the blocked in-place inverse with X = L^-1,
-// and nu = X^T X = H^-1 is a Gram product again (matrix cores, only the tiles and the k-range the triangular shape leaves),
-// added per document into 256 replicated accumulators.  A failed rung of the reference's PD ladder finds A again by
-// re-running the assembly from the b b^T accumulators, which stay in registers until the ladder is through.
+// rows), aliasing the tiles: the blocked Cholesky (block-column updates on the matrix cores, 16-column panels factorised
+// right-looking in registers, the pivot column broadcast through a 64-entry LDS vector) overwrites it with L, the blocked
+// in-place inverse with X = L^-1, and nu = X^T X = H^-1 is a Gram product again (matrix cores, only the tiles and the
+// k-range the triangular shape leaves), added per document into the workgroup's OWN slab of sigma_ss partials in the
+// accumulator-tile layout (plain read-modify-write, prefetched; reduce_sigma_kernel adds the slabs in a fixed order, then
+// untile_sigma_kernel lays the matrix out).  A failed rung of the reference's PD ladder finds A again by re-running the
+// assembly from the b b^T accumulators, which stay in registers until the ladder is through.
 #pragma once
 #include "stm_post_common.h"
 
