@@ -147,9 +147,14 @@ __global__ __launch_bounds__(64) void anchor_project_kernel(const double *Q, int
 // whatever solver finds it -- the reference calls quadprog).  Lawson-Hanson active set on the normal equations, one THREAD per
 // term (5000 small independent problems; scalar code, per-thread state in scratch, the passive-set Cholesky factor in a private
 // slice of global memory).  Anchor terms get their one-hot row (stm.py:261-264).
+// A column whose passive-set factorisation fails (numerically dependent) or that is dropped again by a zero-length step is
+// BANNED until w next changes -- it would otherwise be re-picked and re-factorised until the iteration cap.  Every term ends
+// with a check of the QP's KKT conditions on its result; *nbad counts the terms that fail it (iteration cap, or a violated
+// dual left behind by a ban): the reference's quadprog raises on a P that is not positive definite, stm_spectral_weights
+// reports these the same way instead of returning weights that are not the minimiser.
 constexpr int NNLS_KMAX = 128;
 __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t *anchor, int K, int Vk, double *fac /* [Vk][K][K] */,
-                                                   double *weights /* [Vk][K] */, int32_t *iters_out) {
+                                                   double *weights /* [Vk][K] */, int32_t *nbad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Vk) return;
     double *w_out = weights + (size_t)i * K;
@@ -157,7 +162,6 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
     for (int k = 0; k < K; ++k)
         if (anchor[k] == i) {              // vec[np.where(anchor == i)] = 1
             w_out[k] = 1.0;
-            if (iters_out) iters_out[i] = 0;
             return;
         }
     const double *qi = q + (size_t)i * K;
@@ -165,9 +169,9 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
     auto Pm = [&](int a, int b) -> double { return q[(size_t)anchor[a] * K + b]; };
     double w[NNLS_KMAX], z[NNLS_KMAX], rhs[NNLS_KMAX];
     int idx[NNLS_KMAX];
-    bool inS[NNLS_KMAX];
+    bool inS[NNLS_KMAX], banned[NNLS_KMAX];
     double qmax = 0.0;
-    for (int k = 0; k < K; ++k) { w[k] = 0.0; inS[k] = false; qmax = fmax(qmax, fabs(qi[k])); }
+    for (int k = 0; k < K; ++k) { w[k] = 0.0; inS[k] = false; banned[k] = false; qmax = fmax(qmax, fabs(qi[k])); }
     const double tol = 1e-13 * fmax(qmax, 1e-300) * K;
     double *L = fac + (size_t)i * K * K;    // lower triangular factor of P_SS, row-major with leading dimension K
     int it = 0;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
         int jbest = -1;
         double dbest = tol;
         for (int j = 0; j < K; ++j) {
-            if (inS[j]) continue;
+            if (inS[j] || banned[j]) continue;
             double d = qi[j];
             for (int k = 0; k < K; ++k)
                 if (inS[k]) d -= Pm(j, k) * w[k];
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
                     }
                 }
             }
-            if (!ok) { inS[jbest] = false; w[jbest] = 0.0; break; }   // numerically dependent column: leave it out
+            if (!ok) { inS[jbest] = false; w[jbest] = 0.0; banned[jbest] = true; break; }   // numerically dependent column: leave it out
             for (int a = 0; a < s; ++a) {
                 double t = qi[idx[a]];
                 for (int c = 0; c < a; ++c) t -= L[a * K + c] * rhs[c];
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
             for (int a = 0; a < s; ++a) allpos = allpos && (z[a] > 0.0);
             if (allpos) {
                 for (int a = 0; a < s; ++a) w[idx[a]] = z[a];
+                for (int k = 0; k < K; ++k) banned[k] = false;   // w moved: every column is a candidate again
                 break;
             }
             double alpha = 1.0;
@@ -231,10 +236,21 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
                 w[k] += alpha * (z[a] - w[k]);
                 if (!(w[k] > tol * 1e-3)) { w[k] = 0.0; inS[k] = false; }
             }
+            if (alpha > 0.0) { for (int k = 0; k < K; ++k) banned[k] = false; }
+            else if (!inS[jbest]) { banned[jbest] = true; break; }   // a zero-length step threw the new column out again
         }
     }
     for (int k = 0; k < K; ++k) w_out[k] = w[k];
-    if (iters_out) iters_out[i] = it;
+    // KKT of  min 1/2 w'Pw - q'w, w >= 0:  w >= 0 (by construction), dual d = q - P w <= 0 where w = 0, d = 0 where w > 0
+    bool bad = it >= 3 * K;
+    const double ktol = 1e-8 * fmax(qmax, 1e-300) * K;
+    for (int j = 0; j < K; ++j) {
+        double d = qi[j];
+        for (int k = 0; k < K; ++k)
+            if (inS[k]) d -= Pm(j, k) * w[k];
+        bad = bad || (inS[j] ? fabs(d) > ktol : d > ktol);
+    }
+    if (bad && nbad) atomicAdd(nbad, 1);
 }
 
 }  // namespace stm

@@ -162,6 +162,33 @@ def test_device_gram_anchors_and_beta_match_the_reference(name):
 
 
 @pytest.mark.gpu
+def test_device_qp_with_a_dependent_anchor_row_is_still_a_minimiser():
+    """Two identical anchor rows make P = M M^T singular: the passive-set factorisation of the second one fails, the column
+    is banned (not re-factorised until the iteration cap) and the result must still satisfy the QP's KKT conditions -- a
+    minimiser, if not a unique one; terms whose result does not are reported as STM_ERR_LINALG (what quadprog does with a P
+    that is not positive definite), never returned silently."""
+    from strutopy_amd.engine import HipEstepEngine
+    from strutopy_amd.spectral import gram_inputs, kept_terms
+    g = load_golden("spectral_c1")
+    c = _corpus(g)
+    e = HipEstepEngine(0)
+    wprob, keep = kept_terms(c, 5000)
+    e.spectral_gram(c.N, len(keep), gram_inputs(c, keep))
+    anchor = np.array(e.spectral_anchors(int(g["K"])), dtype=np.float64)
+    anchor[-1] = anchor[0]                                   # a dependent row
+    q = e.spectral_project(anchor)
+    w = e.spectral_weights(anchor)
+    P = q[np.intp(anchor)]
+    free = np.ones(len(q), dtype=bool); free[np.intp(anchor)] = False
+    grad = w @ P - q
+    scale = np.abs(q).max()
+    assert w.min() >= 0 and np.isfinite(w).all()
+    assert grad[free].min() >= -1e-7 * scale and np.abs(grad[free][w[free] > 0]).max() <= 1e-7 * scale
+    e.spectral_release()
+    e.close()
+
+
+@pytest.mark.gpu
 def test_stm_with_spectral_init_on_the_gpu():
     """src/05_train.py's configuration in miniature: init_type="spectral", then EM on the device."""
     from strutopy_amd import STM
