@@ -22,16 +22,19 @@ __global__ __launch_bounds__(256) void moments_kernel(const double *X, const dou
     const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
     const int64_t d0 = (int64_t)blockIdx.x * chunk;
     const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
-    // four documents in flight per thread (independent partial sums, fixed order)
+    // sixteen documents in flight per thread (eight independent partial sums, fixed order): the loop is a chain of memory round trips
     auto sum4 = [&](auto term) {
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int64_t d = d0;
-        for (; d + 3 < d1; d += 4) {
-            const double a = term(d), b = term(d + 1), c = term(d + 2), e = term(d + 3);
-            t0 += a; t1 += b; t2 += c; t3 += e;
+        for (; d + 15 < d1; d += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = term(d + u);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u & 7] += v[u];
         }
-        for (; d < d1; ++d) t0 += term(d);
-        return (t0 + t1) + (t2 + t3);
+        for (; d < d1; ++d) t[0] += term(d);
+        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     };
     for (int slot = threadIdx.x; slot < L; slot += blockDim.x) {
         double t = 0.0;
@@ -69,39 +72,60 @@ __global__ void set_mu_kernel(const double *X, const double *gamma, const double
 }
 
 // per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j] (mu == nullptr: eta^T eta); n <= 128.
-// 256 threads: thread (ty, tx) = (t / 64, t % 64) owns column j = tx + 64 blockIdx.y of rows
-// i = 64 blockIdx.z + ty, ty+4, ...  (grid y = z = ceil(n / 64))
+// 256 threads as 16 x 16: thread (ty, tx) owns the 4 x 4 cells rows 64 blockIdx.z + 4 ty .., columns 64 blockIdx.y + 4 tx ..
+// (grid y = z = ceil(n / 64)) -- eight doubles read from the LDS tile per document and sixteen FMAs, where one column x
+// sixteen rows read seventeen; every cell still adds its documents in order.
 __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, const double *mu, int64_t N,
                                                          int n, double *part) {
     constexpr int TD = 32;  // documents per LDS tile
-    __shared__ double diff[TD][129];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int jc = tx + 64 * blockIdx.y, ib = 64 * blockIdx.z;
-    double acc[16];
+    __shared__ __attribute__((aligned(16))) double diff[TD][130];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int jc = 4 * tx + 64 * blockIdx.y, ib = 4 * ty + 64 * blockIdx.z;
+    double acc[4][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
     const int64_t chunk = (N + gridDim.x - 1) / gridDim.x;
     const int64_t d0 = (int64_t)blockIdx.x * chunk;
     const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
     for (int64_t base = d0; base < d1; base += TD) {
         const int cnt = (int)((d1 - base) < TD ? (d1 - base) : TD);
-        for (int q = threadIdx.x; q < TD * 128; q += 256) {
-            const int dd = q >> 7, i = q & 127;
-            diff[dd][i] = (dd < cnt && i < n) ? (mu ? eta[(base + dd) * n + i] - mu[(base + dd) * n + i] : eta[(base + dd) * n + i]) : 0.0;
+        {   // the tile: all of a thread's sixteen loads in flight, then its stores (a rolled loop is sixteen round trips in sequence)
+            double v[TD * 128 / 256];
+#pragma unroll
+            for (int it = 0; it < TD * 128 / 256; ++it) {
+                const int q = threadIdx.x + 256 * it, dd = q >> 7, i = q & 127;
+                const bool in = dd < cnt && i < n;
+                const int64_t at = in ? (base + dd) * n + i : 0;
+                const double e = eta[at], m = mu ? mu[at] : 0.0;
+                v[it] = in ? (mu ? e - m : e) : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < TD * 128 / 256; ++it) {
+                const int q = threadIdx.x + 256 * it;
+                diff[q >> 7][q & 127] = v[it];
+            }
         }
         __syncthreads();
         for (int dd = 0; dd < cnt; ++dd) {
-            const double cj = diff[dd][jc];
+            const double2 *row = reinterpret_cast<const double2 *>(&diff[dd][0]);
+            const double2 a01 = row[ib >> 1], a23 = row[(ib >> 1) + 1], b01 = row[jc >> 1], b23 = row[(jc >> 1) + 1];
+            const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fma(diff[dd][ib + ty + 4 * r], cj, acc[r]);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = ib + ty + 4 * r;
-        if (i < n && jc < n) part[(size_t)blockIdx.x * n * n + (size_t)i * n + jc] = acc[r];
-    }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = ib + u, j = jc + v;
+            if (i < n && j < n) part[(size_t)blockIdx.x * n * n + (size_t)i * n + j] = acc[u][v];
+        }
 }
 
 // column sums of the word-major beta_ss: part[block][k] = sum over the block's words of bssT[v][k]
