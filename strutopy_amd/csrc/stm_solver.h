@@ -605,6 +605,11 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         const int kq2 = ((KP >> 1) + 3) >> 2;                       // 16-byte pieces per quarter
         if constexpr (DIRECT) {
             if (NdL > 0) STM_WAVE_SYNC();                            // sidx / crow visible to the wave
+            // c / colsum(beta_d) for every word up front (the column sum is a property of the word, P.colsum): inside the tile
+            // loop each tile paid a dependent colsum load and an IEEE division before its first FMA
+#pragma unroll 4
+            for (int vv = lane; vv < NdL; vv += WAVE) wrow[vv] = crow[vv] / csv[sidx[vv]];
+            if (NdL > 0) STM_WAVE_SYNC();
             double g0a[VPL];
 #pragma unroll
             for (int r = 0; r < VPL; ++r) g0a[r] = 0.0;
@@ -614,10 +619,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 tile_store();
                 STM_WAVE_SYNC();
                 if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
-                // (a) c / colsum(beta_d): the column sum is a property of the word (P.colsum)
-                if (lane < nw) wrow[t0 + lane] = crow[t0 + lane] / csv[sidx[t0 + lane]];
-                STM_WAVE_SYNC();
-                // (b) g0 += beta_d[:, tile] @ (c / colsum), lane = topic
+                // g0 += beta_d[:, tile] @ (c / colsum), lane = topic
 #pragma unroll 4
                 for (int w = 0; w < nw; ++w) {
                     const double wq = wrow[t0 + w];
