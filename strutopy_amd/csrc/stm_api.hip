@@ -80,14 +80,22 @@ __global__ void transpose_kernel(const double *in, double *out, int R, int C) {
         if (orow + dy < C && oc < R) out[base + (size_t)(orow + dy) * R + oc] = tile[threadIdx.x][threadIdx.y + dy];
 }
 
-// colsum[a][w] = sum_k betaT[a][w][k], added in topic order (what np.sum(beta_doc_kv, axis=0) of stm.py:954 gives for the word's column)
+// colsum[a][w] = sum_k betaT[a][w][k], added in topic order (what np.sum(beta_doc_kv, axis=0) of stm.py:954 gives for the word's column).
+// A row with an entry that is negative or NaN gets NaN: the E-step's `assert np.all(beta_doc_kv >= 0)` (stm.py:534) fails for
+// exactly the documents that contain such a word, and the solver forms that test from the column sums it loads anyway
+// (!(colsum >= 0)) instead of comparing all K entries of every gathered row again in every document.
 __global__ void beta_colsum_kernel(const double *betaT, int64_t AV, int K, double *colsum) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= AV) return;
     const double *row = betaT + r * K;
     double t = 0.0;
-    for (int k = 0; k < K; ++k) t += row[k];
-    colsum[r] = t;
+    bool bad = false;
+    for (int k = 0; k < K; ++k) {
+        const double v = row[k];
+        bad |= !(v >= 0.0);
+        t += v;
+    }
+    colsum[r] = bad ? __builtin_nan("") : t;
 }
 
 // small device -> pinned-host copy done by the GPU itself (no DMA engine round trip)

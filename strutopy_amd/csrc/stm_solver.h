@@ -360,14 +360,17 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 wait_vmem();
                 STM_WAVE_SYNC();
                 if (ph == 0) {
-                    if (act) { w0 = c0 / cs0; csum += c0; }
+                    // assert beta >= 0 (stm.py:534): a row with a negative or NaN entry carries a NaN column sum (beta_colsum_kernel)
+                    if (act) { w0 = c0 / cs0; csum += c0; bad |= !(cs0 >= 0.0); }
                     wq[lane] = w0;
-                    if (wv == 1) svb[lane] = (lane < NdL) ? cnt_slab / cs_slab : 0.0;
+                    const double wsl = (lane < NdL) ? cnt_slab / cs_slab : 0.0;
+                    if (wv == 1) svb[lane] = wsl;
                     for (int vv = lane; vv < NdL; vv += WAVE) {
                         const double c = vv < WAVE ? cnt_slab : P.counts[p0 + VREG + vv];
                         const double colsum = vv < WAVE ? cs_slab : csv[P.indices[p0 + VREG + vv]];
+                        bad |= !(colsum >= 0.0);
                         crow[vv] = c;
-                        wrow[vv] = c / colsum;
+                        wrow[vv] = vv < WAVE ? wsl : c / colsum;
                         csum += c;
                     }
                     STM_WAVE_SYNC();
@@ -394,7 +397,6 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         for (int u = 0; u < 4; ++u) {
                             const int sr = wi0 + u < nsl ? wi0 + u : nsl - 1;
                             const double sl = slab[(size_t)sr * KP + kk];
-                            bad |= !(sl >= 0.0);
                             v[u] = stg[(j0 + u) * PITCH + kk] * wq[wi0 + u];
                             v[u] = v[u] + sl * svb[wi0 + u];
                         }
@@ -420,11 +422,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 wait_lds();   // every read of the staging area has returned before the next rows are fetched into it
                 STM_WAVE_SYNC();
             }
-#pragma unroll
-            for (int k = 0; k < KR; ++k) bad |= !(breg[k] >= 0.0);
             g0[0] = (lane < n) ? T : 0.0;
             if (NdL > WAVE) {   // slab words beyond the first 64 (uniform; rare)
-                for (int vv = WAVE; vv < NdL; ++vv) bad |= !(slab[(size_t)vv * KP + kk] >= 0.0);
                 for (int k = 0; k < n; ++k) {
                     double t = 0.0;
                     for (int vv = lane + WAVE; vv < NdL; vv += WAVE) t += slab[SI(vv, k)] * wrow[vv];
@@ -608,7 +607,11 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             // c / colsum(beta_d) for every word up front (the column sum is a property of the word, P.colsum): inside the tile
             // loop each tile paid a dependent colsum load and an IEEE division before its first FMA
 #pragma unroll 4
-            for (int vv = lane; vv < NdL; vv += WAVE) wrow[vv] = crow[vv] / csv[sidx[vv]];
+            for (int vv = lane; vv < NdL; vv += WAVE) {
+                const double cs = csv[sidx[vv]];
+                bad |= !(cs >= 0.0);     // assert beta >= 0 (stm.py:534): NaN column sum <=> the row has a negative or NaN entry
+                wrow[vv] = crow[vv] / cs;
+            }
             if (NdL > 0) STM_WAVE_SYNC();
             double g0a[VPL];
 #pragma unroll
@@ -627,7 +630,6 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     for (int r = 0; r < VPL; ++r)
                         if (lane + WAVE * r < KP) {
                             const double bv = slab[(size_t)w * KP + lane + WAVE * r];
-                            bad |= !(bv >= 0.0);     // assert beta >= 0 (stm.py:534): every entry of the tile passes here
                             g0a[r] = fma(bv, wq, g0a[r]);
                         }
                 }
