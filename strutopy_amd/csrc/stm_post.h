@@ -205,6 +205,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
 
         if (DBG && P.prof) tp[1] = (long long)__builtin_readcyclecounter();
         double csum = 0.0, ll = 0.0, rowc = 0.0;
+        double Lst = 1.0, cst = 0.0;   // a (word, tile) pair's theta @ a and count waiting for the next batched logarithm
         bool sbad = false;
         v4d acc[NT];
 #pragma unroll
@@ -246,8 +247,17 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 const bool valid = w < nw, own = q == 0;
                 const double c = valid ? c0 : 0.0, sq = sqrt(c);
                 const double wq = valid ? sq / Sw : 0.0;   // sqrt(c) / colsum: update_z, stm.py:1115, and the factor of b, stm.py:1001
-                const double lg = log_pos(Lw) * c;
-                ll += (valid && own) ? lg : 0.0;
+                // c * log(theta @ a) (stm.py:1095): the quad's four lanes all hold the word's Lw -- lane q keeps the one of every
+                // fourth tile, and the logarithm is taken once per four tiles over 64 distinct (word, tile) pairs
+                {
+                    const bool mine = ((t0 / TW) & 3) == q;     // t0 / TW: the tile's number
+                    Lst = mine ? (valid ? Lw : 1.0) : Lst;
+                    cst = mine ? c : cst;
+                    if (((t0 / TW) & 3) == 3) {   // uniform
+                        ll += cst * log_pos(Lst);
+                        Lst = 1.0; cst = 0.0;
+                    }
+                }
                 csum += own ? c : 0.0;
                 if (own) *reinterpret_cast<double2 *>(wpar + 2 * w) = make_double2(wq, sq);
                 // phi = beta * theta * r (stm_betass.h): r = exp-sum * c / S, in update_z's association (sqrt(c) / S) * sqrt(c).
@@ -292,8 +302,10 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 for (int s = 0; s < TW / 4; ++s)
 #pragma unroll
                     for (int b = 0; b < NB; ++b) f[s][b] = tr[4 * s * PITCH + 16 * b];
+                // (groups of four words beyond the document's last word are rows of zeros: the last tile skips them)
 #pragma unroll
                 for (int s = 0; s < TW / 4; ++s) {
+                    if (4 * s >= nw) break;   // uniform
                     int t = 0;
 #pragma unroll
                     for (int bi = 0; bi < NB; ++bi)
@@ -306,6 +318,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                     double h0 = 0.0, h1 = 0.0;
 #pragma unroll
                     for (int w = 0; w < TW; w += 2) {
+                        if (w >= nw) break;   // uniform
                         h0 = fma(own[w * PITCH], rem[w * PITCH], h0);
                         h1 = fma(own[(w + 1) * PITCH], rem[(w + 1) * PITCH], h1);
                     }
@@ -317,6 +330,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[3] += cy - cy0; }
             idx0 = idx1; c0 = c1; sl0 = sl1; idx1 = idx2; c1 = c2; sl1 = sl2;
         }
+        ll += cst * log_pos(Lst);   // the pairs of the last, incomplete batch of tiles (lanes without one: 0 * log(1))
         STM_POST_SYNC();
         sth[lane] = isk ? ths : 0.0;   // inside region 0, behind the matrix: the tiles are done
         if (DBG && P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * PROF_SLOTS + 24 + q] = tq[q];
