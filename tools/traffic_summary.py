@@ -34,7 +34,7 @@ out = {"_workload": {"docs": N, "vocab": int(sys.argv[6]) if len(sys.argv) > 6 e
                      "words": int(sys.argv[7]) if len(sys.argv) > 7 else 150},
        "_units": "bytes per E-step (all dispatches of the kernel in one EM iteration)", "_fetch_calibration": cal,
        "_note": "FETCH_SIZE*1024*calibration + WRITE_SIZE*1024; calibration = known bytes of covariance_kernel / its FETCH_SIZE",
-       "_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --steps 1 --warmup 0 --cpu-sample 0` (tools/profile_r03.sh)"}
+       "_source": "EM iteration 0 ONLY: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --steps 1 --warmup 0 --cpu-sample 0` (tools/profile_r03.sh)"}
 for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, 0.0) * 1024 * (cal or 1.0)
     w = write.get(k, 0.0) * 1024
