@@ -333,7 +333,7 @@ static int plan_solver(stm_handle *h) {
 static int build_word_major(stm_handle *h) {
     const int64_t N = h->N, nnz = h->nnz;
     const size_t R = (size_t)h->A * (size_t)h->V;
-    const int64_t gdocs = std::max<int64_t>(1, stm::BETASS_GROUP_BYTES / ((int64_t)h->K * 8));
+    const int64_t gdocs = std::max<int64_t>(1, (int64_t)env_int("STM_BETASS_GROUP_KB", stm::BETASS_GROUP_BYTES >> 10) * 1024 / ((int64_t)h->K * 8));
     int64_t G = std::max<int64_t>(1, (N + gdocs - 1) / gdocs);
     G = std::min<int64_t>(G, 64);
     G = std::min<int64_t>(G, std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)std::max<size_t>(R * (size_t)h->K, 1)));   // <= 2 GB of partial sums
@@ -692,7 +692,10 @@ static int bss_enqueue(stm_handle *h) {
     const int64_t wpg = (bp.R + stm::BETASS_ROWS - 1) / stm::BETASS_ROWS, bpg = (wpg + 3) / 4;
     h->bss_pair ^= 1; h->bss_pair_used = true;
     HIP_TRY(hipEventRecord(h->ev_b[2 * h->bss_pair], h->stream));
-    hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+    // even K: two rows per load instruction (needs 16-byte aligned rows and N K 8 < 4 GiB for its 32-bit offsets)
+    const bool two = (K % 2 == 0) && (size_t)h->N * K * 8 < ((size_t)1 << 32) && env_int("STM_BETASS_TWO", 1) != 0;
+    if (two) hipLaunchKernelGGL((stm::beta_ss_part2_kernel<8, stm::BETASS_ROWS>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+    else hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
     hipLaunchKernelGGL(stm::beta_ss_reduce_kernel, dim3((unsigned)((bp.R * K + 255) / 256)), dim3(256), 0, h->stream, bp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_b[2 * h->bss_pair + 1], h->stream));

@@ -33,8 +33,8 @@ struct BetaSsParams {
     double *beta_ssT;         // [A][V][K]
 };
 
-constexpr int BETASS_GROUP_BYTES = 1 << 20;   // theta bytes per document group
-constexpr int BETASS_ROWS = 4;                // rows per wave (4 / 8 / 16 and 8 / 16 loads in flight measured: 0.56 - 0.73 ms at configs[1])
+constexpr int BETASS_GROUP_BYTES = 2 << 20;   // theta bytes per document group (0.5 / 1 / 2 / 4 MB measured at configs[1]: 4.25 / 4.14 / 4.11 / 4.29 ms post + pass; STM_BETASS_GROUP_KB overrides)
+constexpr int BETASS_ROWS = 4;                // rows per wave (2 / 4 / 8 / 16 rows and 4 / 8 / 12 / 16 loads in flight measured; 4 rows, 8 loads)
 
 // One wave per (ROWS rows, group), lane = topic; blockIdx is group-major.  A cell's (document, r) pairs are fetched
 // lane-parallel -- the next cell's while the current one is consumed -- and handed out with v_readlane, DEPTH theta rows in flight.
@@ -90,6 +90,80 @@ __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
         if (nq != q) {   // the cell is complete
             if (lane < K) P.part[((size_t)g * R + (size_t)(r0 + q)) * K + lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+        }
+        q = nq; e0 = n0; e1 = n1; dl = dn; rl = rn;
+    }
+}
+
+// The same pass for even K: two theta rows per load instruction.  A lane owns one 16-byte piece of a row (two topics), lanes
+// 0 .. K/2-1 serve the even entries of a batch and lanes K/2 .. K-1 the odd ones: half the memory instructions (each moves 2 x 8K
+// bytes), half the FMAs' instruction count, twice the rows in flight per wave for the same DEPTH -- the pass is bound by how many
+// gathers the CU keeps in the air.  A cell's sum is (even entries) + (odd entries), each in four round-robin partial sums.
+template <int DEPTH, int ROWS>
+__global__ __launch_bounds__(256) void beta_ss_part2_kernel(BetaSsParams P) {
+    const int lane = threadIdx.x & 63;
+    const int K = P.K, G = P.G, CH = K >> 1;
+    const int64_t R = P.R, wpg = (R + ROWS - 1) / ROWS;
+    const int64_t bpg = (wpg + 3) / 4;
+    const int g = (int)(blockIdx.x / bpg);
+    const int64_t wv = (blockIdx.x % bpg) * 4 + (threadIdx.x >> 6);
+    if (wv >= wpg) return;
+    const int64_t r0 = wv * ROWS, r1 = r0 + ROWS < R ? r0 + ROWS : R;
+    const int rr = lane >= CH ? 1 : 0, cc = lane - rr * CH;
+    const bool act = lane < 2 * CH;
+    const unsigned coff = 16u * (unsigned)(act ? cc : 0);
+    const char *th0 = reinterpret_cast<const char *>(P.theta);
+    const unsigned K8 = 8u * (unsigned)K;
+    const int nr = (int)(r1 - r0);
+    const int lo_l = lane < nr ? P.cptr[(r0 + lane) * G + g] : 0, hi_l = lane < nr ? P.cptr[(r0 + lane) * G + g + 1] : 0;
+    auto fetch = [&](int e0, int e1, int &d, double &r) __attribute__((always_inline)) {   // entries [e0, min(e1, e0 + 64))
+        const bool in = e0 + lane < e1;
+        const int el = in ? e0 + lane : 0;                 // lanes beyond the batch read entry 0 and carry r = 0
+        d = P.wm_doc[el];
+        const double rv = P.rw[el];
+        r = in ? rv : 0.0;
+    };
+    int q = 0;
+    int e0 = __builtin_amdgcn_readlane(lo_l, 0), e1 = __builtin_amdgcn_readlane(hi_l, 0);
+    int dl, dn = 0;
+    double rl, rn = 0.0;
+    fetch(e0, e1, dl, rl);
+    double ax[4] = {0.0, 0.0, 0.0, 0.0}, ay[4] = {0.0, 0.0, 0.0, 0.0};
+    while (q < nr) {
+        const int cnt = e1 - e0 < WAVE ? e1 - e0 : WAVE;
+        int nq = q, n0 = e0 + WAVE, n1 = e1;
+        if (n0 >= e1) {
+            nq = q + 1;
+            if (nq < nr) { n0 = __builtin_amdgcn_readlane(lo_l, nq); n1 = __builtin_amdgcn_readlane(hi_l, nq); }
+        }
+        if (nq < nr) fetch(n0, n1, dn, rn);
+        const unsigned doff = (unsigned)dl * K8;             // (N K 8 < 4 GiB: checked by the host)
+        const int rlo = __double2loint(rl), rhi = __double2hiint(rl);
+        for (int u = 0; u < cnt; u += 2 * DEPTH) {          // DEPTH loads = 2 DEPTH entries; the entries beyond cnt carry r = 0
+            double2 th[DEPTH];
+            double r[DEPTH];
+#pragma unroll
+            for (int t = 0; t < DEPTH; ++t) {
+                const int src = 4 * ((u + 2 * t + rr) & (WAVE - 1));
+                const unsigned o = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)doff) + coff;
+                th[t] = *reinterpret_cast<const double2 *>(th0 + o);
+                r[t] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, rhi), __builtin_amdgcn_ds_bpermute(src, rlo));
+            }
+#pragma unroll
+            for (int t = 0; t < DEPTH; ++t) {
+                ax[t & 3] = fma(th[t].x, r[t], ax[t & 3]);
+                ay[t & 3] = fma(th[t].y, r[t], ay[t & 3]);
+            }
+        }
+        if (nq != q) {   // the cell is complete: even-entry lanes add their odd-entry partners' sums
+            double sx = (ax[0] + ax[1]) + (ax[2] + ax[3]), sy = (ay[0] + ay[1]) + (ay[2] + ay[3]);
+            const int partner = 4 * (lane + CH < WAVE ? lane + CH : lane);
+            const double ox = __hiloint2double(__builtin_amdgcn_ds_bpermute(partner, __double2hiint(sx)), __builtin_amdgcn_ds_bpermute(partner, __double2loint(sx)));
+            const double oy = __hiloint2double(__builtin_amdgcn_ds_bpermute(partner, __double2hiint(sy)), __builtin_amdgcn_ds_bpermute(partner, __double2loint(sy)));
+            if (lane < CH)
+                *reinterpret_cast<double2 *>(P.part + ((size_t)g * R + (size_t)(r0 + q)) * K + 2 * lane) = make_double2(sx + ox, sy + oy);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ax[t] = 0.0; ay[t] = 0.0; }
         }
         q = nq; e0 = n0; e1 = n1; dl = dn; rl = rn;
     }
