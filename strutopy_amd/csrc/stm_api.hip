@@ -36,8 +36,10 @@ int fail(int code, const std::string &msg) {
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
+        if (e_ != hipSuccess) {                                                             \
+            (void)hipGetLastError(); /* the runtime's sticky error must not fail the NEXT call's hipGetLastError() check */ \
             return fail(STM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+        }                                                                                   \
     } while (0)
 
 template <class T>
@@ -258,7 +260,7 @@ static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, b
 static int slab_row(int K) { return ((std::max(K, 2) - 2 + 3) / 4) * 4 + 2; }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
-constexpr size_t LDS_STATIC = 3584;   // static LDS of the solver kernel (se, sv, sw, mailbox), rounded up
+constexpr size_t LDS_STATIC = 4096;   // static LDS of the solver kernel (se, sv, sw, mailbox, scalar state) when the runtime cannot be asked
 
 // Cut the longest-first document order into launches of equal LDS occupancy.
 static int plan_solver(stm_handle *h) {
@@ -286,8 +288,16 @@ static int plan_solver(stm_handle *h) {
         if (h->direct) return (size_t)16 * KP * sizeof(double) + (size_t)nd * (2 * sizeof(double) + sizeof(int32_t)) + 16;
         return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double) + h_lds;
     };
+    // the kernel's own static LDS (what a workgroup needs is static + dynamic: a constant here went stale when the scalar
+    // line-search state moved into LDS, and a document just below the limit then failed in hipFuncSetAttribute)
+    size_t lds_static = LDS_STATIC;
+    {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void *)solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma)) == hipSuccess) lds_static = fa.sharedSizeBytes;
+        else (void)hipGetLastError();
+    }
     auto per_cu = [&](int nd) -> int {
-        const size_t b = ((lds_of(nd) + LDS_STATIC + 511) / 512) * 512;
+        const size_t b = ((lds_of(nd) + lds_static + 511) / 512) * 512;
         if (mode == 2 || b > LDS_PER_CU) return 0;
         if (h->direct) return (int)std::min<size_t>((size_t)cmax, LDS_PER_CU / b);
         // K > 64: one wave per document and nothing to hide its latencies but other documents -- below four
@@ -321,6 +331,7 @@ static int plan_solver(stm_handle *h) {
     if (max_dyn > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_dyn);
+        if (e != hipSuccess) (void)hipGetLastError();
         if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
     h->slab_beta_len = glob_len;

@@ -296,6 +296,32 @@ def test_documents_longer_than_the_lds(oracle):
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), "long documents")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [18, 50])
+def test_documents_at_the_edge_of_the_lds(oracle, K):
+    """Document lengths that walk across the point where static + dynamic LDS of the two-wave solver reach 160 KB: the plan
+    must count the kernel's real static LDS (asked from the runtime) -- with a stale constant a document a few words below
+    the limit was planned for the LDS form and failed in hipFuncSetAttribute (found by tools/fuzz_parity.py)."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(K)
+    V = 3000
+    n = K - 1
+    kreg = 32 if K <= 32 else 50
+    kp = ((kreg - 2 + 3) // 4) * 4 + 2                       # slab row length (stm_api.hip: slab_row)
+    edge = 128 + (160 * 1024 - n * n * 8 - 3600) // ((kp + 2) * 8)   # words at which the workgroup's LDS is about 160 KB
+    lens = [edge + d for d in (-3, -2, -1, 0, 1, 2)] + [100, 130]
+    docs = [np.sort(rng.choice(V, L, replace=False)) for L in lens]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 4, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    N = len(lens)
+    mu = rng.normal(0, 0.1, size=(N, n)); eta = rng.normal(0, 0.1, size=(N, n))
+    siginv, sigent = oracle.preamble(np.eye(n) * 2.0)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    _check(estep_host(*args), oracle.estep(*args, nthreads=0), "documents at the LDS limit")
+
+
 def test_invalid_inputs_raise_like_the_reference():
     from strutopy_amd.engine import HipEstepEngine, estep_host
     g = load_golden("toy_ctm")
