@@ -134,7 +134,12 @@ int stm_mstep_update_beta(stm_handle *h);
 /* One EM iteration on resident state with ONE host wait (what STM.expectation_maximization runs):
  *   stm_em_begin   enqueues the E-step (as stm_estep), the moments (as stm_mstep_moments) and, when a communicator is
  *                  attached, the all-reduce of the packed buffer; waits once; returns the (reduced) bound, sigma_ss
- *                  and moments, and reports the E-step's errors like stm_estep.
+ *                  and moments, and reports the E-step's errors like stm_estep.  Every fallible host-side step (sizes,
+ *                  allocations) comes before anything is enqueued, and a rank's device error flag travels in slot 1 of
+ *                  the packed scalars: with a communicator EVERY rank returns an error in the iteration in which any rank's
+ *                  E-step failed.  Without a communicator the word-major beta_ss pass (K <= 64) is enqueued behind the
+ *                  read-back and may still be running when the call returns; whatever touches beta_ss next on the handle
+ *                  (stm_em_finish, stm_mstep_update_beta, stm_get_beta_ss, ...) is ordered behind it.
  *   stm_em_finish  enqueues mu (regression on gamma, or the constant mean_eta when gamma == NULL) and beta from the
  *                  (reduced) beta_ss -- stm_mstep_set_mu + stm_mstep_update_beta without their waits; whatever is called
  *                  next on the handle is ordered behind them. */
