@@ -791,6 +791,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
     int nrep = h->nrep;
     size_t slab = (size_t)h->n * h->n;
+    bool rem_used = false;   // K <= 64 post kernel instantiated with REM = 1 (decides the layout of its nu slabs)
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
@@ -828,6 +829,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
                         : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
         }
         const bool big = K > stm::PT;   // two topics per lane (stm_post_big.h)
+        rem_used = rem && !big;
         pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
         const int nbb = (n + 15) / 16;
         const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
@@ -849,7 +851,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
         nrep = big ? h->nrep : (int)grid;
         const int nbc = (n + 15) / 16;
-        slab = big ? (size_t)n * n : (size_t)(nbc * (nbc + 1) / 2) * 256;   // post_kernel: accumulator-tile layout
+        // post_kernel: accumulator-tile layout; with REM the last column has a slot of its own instead of a block column of tiles
+        slab = big ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
         if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
         HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
         pp.sigma_part = h->d_sigma_part; pp.nrep = nrep;
@@ -870,7 +873,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     } else {   // post_kernel's slabs: summed in their tile layout, then laid out as the matrix
         double *tiles = h->d_sigma_part + (size_t)nrep * slab;
         if (int rc = reduce_copies(h, h->d_sigma_part, nrep, (int)slab, tiles)) return rc;
-        hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss);
+        hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss, rem_used ? 1 : 0);
     }
     if (int rc = ensure(&h->d_red, &h->red_len, (size_t)BOUND_BLOCKS)) return rc;   // (first BOUND_BLOCKS slots: the bound's block sums)
     hipLaunchKernelGGL(stm::bound_partial_kernel, dim3(BOUND_BLOCKS), dim3(256), 0, h->stream, (const double *)h->d_bound, h->N, h->d_red);

@@ -101,7 +101,10 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
     double *srd = vec;               // inverse: 1 / diag(L)
     const double *S = P.siginv;
     const bool sdiag = P.siginv_diag != 0;
-    double *sig_acc = P.sigma_part + (size_t)blockIdx.x * (size_t)(NBC * (NBC + 1) / 2) * 4 * WAVE;   // this workgroup's own sum of nu, tile layout
+    // this workgroup's own sum of nu, tile layout: NBV (NBV + 1) / 2 tiles of the full blocks' upper triangle and, with REM, one
+    // more 256-double slot whose first 64 entries hold the last column (nu[i][R0] in entry i)
+    constexpr int NBV = REM ? NB : NBC, NU_TILES = NBV * (NBV + 1) / 2 + REM;
+    double *sig_acc = P.sigma_part + (size_t)blockIdx.x * (size_t)NU_TILES * 4 * WAVE;
     bool isn = lane < n, isk = lane < K;
     int fr = lane & 15, fq = lane >> 4;  // MFMA fragment coordinates
     // The lane id is re-read behind an opaque move at the start of every phase: otherwise the lane-dependent LDS
@@ -716,7 +719,13 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         // nobody else touches the slab.  Cells beyond n are exact zeros.  untile_sigma_kernel undoes the layout.
         double *nu_doc = (DBG && P.nu_out) ? P.nu_out + (size_t)doc * n * n : nullptr;
         if (upper) {   // nu = diag(1 / L_ii^2): element (i, i) sits in tile (b, b) at r = ((i & 15) - fq) / 4, lane = (fq, fr = i & 15)
-            for (int bb = 0; bb < NBC; ++bb) {
+            if (REM && lane == R0) {
+                const double v = srd[R0] * srd[R0];
+                sig_acc[(size_t)(NU_TILES - 1) * 4 * WAVE + R0] += v;
+                if (DBG && nu_doc)
+                    for (int j = 0; j < n; ++j) nu_doc[(size_t)R0 * n + j] = (j == R0) ? v : 0.0;
+            }
+            for (int bb = 0; bb < NBV; ++bb) {
                 const int i = bb * 16 + fr, r = (fr - fq) >> 2;
                 if (((fr - fq) & 3) == 0 && fr >= fq && i < n) {
                     const double v = srd[i] * srd[i];
@@ -726,13 +735,21 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 }
             }
         } else {
+            if (REM) {   // the last column on the VALU: nu[i][R0] = X[R0][i] X[R0][R0] (row R0 is X's only row with an entry there)
+                const int ic = isn ? lane : nm1;
+                double *cell = sig_acc + (size_t)(NU_TILES - 1) * 4 * WAVE + lane;
+                const double oldv = *cell;
+                const double v = isn ? M[RS(R0) + ic] * M[RS(R0) + R0] : 0.0;
+                *cell = oldv + v;
+                if (DBG && nu_doc && isn) { nu_doc[(size_t)lane * n + R0] = v; nu_doc[(size_t)R0 * n + lane] = v; }
+            }
 #pragma unroll 1
-            for (int bj = 0; bj < NBC; ++bj) {
+            for (int bj = 0; bj < NBV; ++bj) {
                 const int rj = bj * 16 + fr, rjc = rj < n ? rj : nm1;
                 double *slab = sig_acc + (size_t)(bj * (bj + 1) / 2) * 4 * WAVE + lane;
-                v4d an[NBC], old[NBC];
+                v4d an[NBV], old[NBV];
 #pragma unroll
-                for (int b = 0; b < NBC; ++b) {
+                for (int b = 0; b < NBV; ++b) {
                     an[b] = (v4d){0.0, 0.0, 0.0, 0.0};
                     if (b <= bj) {
 #pragma unroll
@@ -743,19 +760,19 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 for (int s4 = bj * 16; s4 < n; s4 += 4) {
                     const int col = s4 + fq, colc = col < n ? col : nm1;
                     const double *xr = M + RS(colc);
-                    double f[NBC];
+                    double f[NBV];
 #pragma unroll
-                    for (int b = 0; b < NBC; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
-                    const double fb = (col < n && rj < n && col >= rj) ? f[NBC - 1] : 0.0;   // f[NBC - 1] is always block bj's own fragment
+                    for (int b = 0; b < NBV; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
+                    const double fb = (col < n && rj < n && col >= rj) ? f[NBV - 1] : 0.0;   // f[NBV - 1] is always block bj's own fragment
 #pragma unroll
-                    for (int b = 0; b < NBC; ++b) {
+                    for (int b = 0; b < NBV; ++b) {
                         if (b > bj) break;
                         const double fa = (b == bj) ? fb : ((col < n) ? f[b] : 0.0);
                         an[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, an[b], 0, 0, 0);
                     }
                 }
 #pragma unroll
-                for (int b = 0; b < NBC; ++b) {
+                for (int b = 0; b < NBV; ++b) {
                     if (b > bj) break;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

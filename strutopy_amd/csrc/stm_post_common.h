@@ -132,12 +132,18 @@ __global__ void mirror_blocks_kernel(double *a, int n) {
 
 // sigma_ss from the accumulator-tile layout the K <= 64 post kernel sums nu in (stm_post.h): tile (b, bj), b <= bj, at
 // bj (bj + 1) / 2 + b holds element (16 b + fq + 4 r, 16 bj + fr) at [r][lane = 16 fq + fr]; cells below the diagonal
-// take their mirror image (nu is symmetric, and only the upper block triangle is accumulated)
-__global__ void untile_sigma_kernel(const double *tiles, int n, double *out) {
+// take their mirror image (nu is symmetric, and only the upper block triangle is accumulated); rem: n = 16 NB + 1 and the
+// last column sits in a slot of its own (post_kernel<NB, 1, ...>)
+__global__ void untile_sigma_kernel(const double *tiles, int n, double *out, int rem) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n * n) return;
     int i = q / n, j = q % n;
     if (i > j) { const int t = i; i = j; j = t; }
+    if (rem && j == n - 1) {   // the column beyond the full blocks: its own slot behind their tiles, entry i
+        const int nb = (n - 1) >> 4;
+        out[q] = tiles[(size_t)(nb * (nb + 1) / 2) * 256 + i];
+        return;
+    }
     const int b = i >> 4, bj = j >> 4, il = i & 15, fr = j & 15;
     out[q] = tiles[((size_t)(bj * (bj + 1) / 2 + b) * 4 + (il >> 2)) * 64 + (il & 3) * 16 + fr];
 }
