@@ -389,8 +389,9 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             if (isn) M[RS(lane) + lane] = diagA;
             STM_POST_SYNC();
             bool ok = true;
+            constexpr int NBP = REM ? NB : NBC;   // REM: the one column beyond the full blocks is a single pivot, below
 #pragma unroll 1
-            for (int p = 0; p < NBC && ok; ++p) {
+            for (int p = 0; p < NBP && ok; ++p) {
                 const int J0 = 16 * p;
                 relane();
                 long long cq = (DBG && P.prof) ? (long long)__builtin_readcyclecounter() : 0;
@@ -483,6 +484,15 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 }
                 STM_POST_SYNC();
                 if (DBG && P.prof) { const long long c1 = __builtin_readcyclecounter(); tcc[3] += c1 - cq; }
+            }
+            if (REM && ok) {   // the last pivot: A[R0][R0] - sum_k L[R0][k]^2 (row R0 is final: every panel stored its part of it)
+                relane();
+                const double l = lane < R0 ? M[RS(R0) + lane] : 0.0;
+                const double d = M[RS(R0) + R0] - wave_sum(l * l);
+                double ljj, rjj;
+                sqrt_and_rsqrt(d, ljj, rjj);
+                if (lane == R0) Ldiag = ljj;
+                if (wave_any(lane == R0 && !(d > PIVOT_TOL * diagA))) ok = false;
             }
             return ok;
         };
