@@ -28,6 +28,9 @@
 #ifndef STM_EVAL_GROUP
 #define STM_EVAL_GROUP 8   // topics per scheduling group of the evaluation's register pass
 #endif
+#ifndef STM_MOM_GROUP
+#define STM_MOM_GROUP 2    // ... of the moment pass (three broadcast vectors, six sums)
+#endif
 
 namespace stm {
 
@@ -64,7 +67,8 @@ struct SolverParams {
     int lds_doubles;        // dynamic LDS of this launch, in doubles (debug bit3 poisons it)
     int zrow;               // DMA form: index of the all-zero row behind the last row of betaT (A * V)
     int debug_flags;        // bit0: skip the BFGS loop (bring-up aid); bit1: no line-search cuts, bit2: no reuse of DCSRCH's first
-                            // evaluation by wolfe2 (every evaluation scipy makes is made: A/B check of the shortcuts)
+                            // evaluation by wolfe2 (every evaluation scipy makes is made: A/B check of the shortcuts); bit4: no moment
+                            // pass in front of the first search (the cuts of rounds 1-2 only)
     long long *prof;        // optional [N][PROF_SLOTS] shader-clock totals per document: [0] init, [1] evaluations, [2] state machine,
                             // [3] BFGS update, [8+st] cycles in state st (low 40 bits) and visits of it (bits 40..)
 };
@@ -72,7 +76,7 @@ struct SolverParams {
 enum : int {
     S_INIT_DONE = 0, S_OUTER_TOP, S_W1_START, S_W1_ITER, S_W2_START, S_W2_FIRST, S_W2_TOP,
     S_W2_GOT_G, S_W2_GOT_F, S_ZOOM_TOP, S_ZOOM_GOT_F, S_ZOOM_GOT_G, S_ZOOM_NEXT, S_ACCEPT,
-    S_ACCEPT2, S_FINISH
+    S_ACCEPT2, S_FINISH, S_MOMENTS   // (S_MOMENTS last: the profile slots of the other states keep their numbers)
 };
 
 // scipy/optimize/_dcsrch.py:502-728 dcstep (wave-uniform scalars).  State in and out BY VALUE and
@@ -229,8 +233,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     constexpr int TWS = 16;   // DIRECT: words per LDS tile
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];  // slab[ld][KP] | crow[ld] | wrow[ld] | H[n][n] (NW = 2)
     __shared__ __attribute__((aligned(16))) double se[KMAX + 2];  // exp(eta~ - m), broadcast to every lane
-    __shared__ double sv[KMAX + 1];  // vector broadcast (matvec operand / s)
-    __shared__ double sw[KMAX + 1];  // vector broadcast (w = H y)
+    __shared__ __attribute__((aligned(16))) double sv[KMAX + 2];  // vector broadcast (matvec operand / s; exp(eta~ - m) p~ of the moment pass)
+    __shared__ __attribute__((aligned(16))) double sw[KMAX + 2];  // vector broadcast (w = H y; exp(eta~ - m) p~^2 of the moment pass)
     __shared__ double svb[NW == 2 ? KMAX + 1 : 1];  // wave 1's private broadcast vector
     // wave 0 <-> wave 1 mailbox (NW = 2)
     __shared__ double xch_xt[NW == 2 ? WAVE : 1];   // trial point
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     __shared__ double xch_res[8];                   // [0] data-term share, [1] quadratic form, [2] m, [4..5] word-count shares, [6..7] rho, cc of a BFGS update
     __shared__ int xch_cmd[4];
     __shared__ double ss[64];                       // the scalar state of the line searches (struct ud; wave 0's, Ndoc both waves')
-    enum : int { U_old_fval, U_old_old_fval, U_gnorm, U_phi0, U_old_phi0, U_derphi0, U_Lb, U_Lv, U_prange, U_stx, U_fx, U_gx, U_sty, U_fy, U_gy, U_stmin, U_stmax, U_width, U_width1, U_finit, U_ginit, U_gtest, U_w1_a1, U_w1_f1, U_alpha0, U_alpha1, U_phi_a0, U_phi_a1, U_derphi_a0, U_a_lo, U_a_hi, U_phi_lo, U_phi_hi, U_derphi_lo, U_phi_rec, U_a_rec, U_a_j, U_acc_alpha, U_acc_f, U_alpha, U_fval, U_dval, U_cache_f, U_Ndoc, U_sig_lmax, U_COUNT };
+    enum : int { U_old_fval, U_old_old_fval, U_gnorm, U_phi0, U_old_phi0, U_derphi0, U_Lb, U_Lv, U_prange, U_stx, U_fx, U_gx, U_sty, U_fy, U_gy, U_stmin, U_stmax, U_width, U_width1, U_finit, U_ginit, U_gtest, U_w1_a1, U_w1_f1, U_alpha0, U_alpha1, U_phi_a0, U_phi_a1, U_derphi_a0, U_a_lo, U_a_hi, U_phi_lo, U_phi_hi, U_derphi_lo, U_phi_rec, U_a_rec, U_a_j, U_acc_alpha, U_acc_f, U_alpha, U_fval, U_dval, U_cache_f, U_Ndoc, U_sig_lmax, U_mvar0, U_mD1, U_mD2, U_mg0p, U_mqx, U_COUNT };
     static_assert(U_COUNT <= 64, "scalar state");                      // [0] request bits (1 f, 2 g, 4 exit, 8 BFGS update (16: from the identity)), [1..2] bad-beta flags
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = NW == 2 ? uni((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to the compiler as such (scalar branches)
@@ -540,8 +544,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         if (P.prof && NW == 2 && wv == 1 && lane == 0) P.prof[doc * PROF_SLOTS + 7] = t_g1 - t_begin;   // wave 1: register rows + slab
         }   // !DMA
         // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
-        if (wv == 0)
+        if (wv == 0) {
             for (int i = lane; i < KMAX + 2; i += WAVE) se[i] = 0.0;
+            if (lane < 2) { sv[KMAX + lane] = 0.0; sw[KMAX + lane] = 0.0; }   // the moment pass reads all three up to KP
+        }
         csum_all = wave_sum(csum);
         bool bad_all = wave_any(bad);
         if (NW == 2) {
@@ -862,20 +868,20 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             }
             return part;
         };
-        // (eta - mu)^T siginv (eta - mu), wave-summed
-        auto quad_F = [&]() __attribute__((always_inline)) -> double {
+        // d^T siginv d, wave-summed; dv(r) = the lane's component lane + 64 r of d
+        auto quad_of = [&](auto dv) __attribute__((always_inline)) -> double {
             double q = 0.0;
             if (sdiag) {
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
                     if (lane + WAVE * r < n) {
-                        const double d = xt[r] - mu[r];
+                        const double d = dv(r);
                         q += (d * sd[r]) * d;
                     }
             } else {
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
-                    if (lane + WAVE * r < n) svx[lane + WAVE * r] = xt[r] - mu[r];
+                    if (lane + WAVE * r < n) svx[lane + WAVE * r] = dv(r);
                 STM_WAVE_SYNC();
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) {
@@ -889,6 +895,61 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 STM_WAVE_SYNC();
             }
             return wave_sum(q);
+        };
+        // (eta - mu)^T siginv (eta - mu)
+        auto quad_F = [&]() __attribute__((always_inline)) -> double {
+            return quad_of([&](int r) __attribute__((always_inline)) -> double { return xt[r] - mu[r]; });
+        };
+        // Moment pass of the two-wave form (see S_OUTER_TOP): with e = exp(eta~ - m) in se[], e p~ in sv[] and e p~^2 in sw[],
+        // the mean and the variance of p~ under q_w(k) ~ beta_d[k, w] e_k for each of this wave's words, summed with the word
+        // counts: d1 = sum_w c_w E_{q_w}[p~] (the derivative of f's data term along p), d2 = sum_w c_w Var_{q_w}(p~) (its
+        // second derivative).  Per lane; the caller wave-sums.  Feeds a sufficient condition only -- nothing scipy computes.
+        auto moments_words = [&](double &d1, double &d2, const int NdL) __attribute__((always_inline)) {
+            d1 = 0.0; d2 = 0.0;
+            if constexpr (NW == 2) {
+                const double2 *se2 = reinterpret_cast<const double2 *>(se);
+                const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
+                const double2 *sw2 = reinterpret_cast<const double2 *>(sw);
+                {
+                    // the word's count again from memory (L2): a second use of c0 at this site costs 225 spilled registers
+                    const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KR; k += 2) {
+                        if (k % STM_MOM_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+                        const double2 e = se2[k / 2], u = sv2[k / 2], v = sw2[k / 2];
+                        a0 = fma(e.x, breg[k], a0); a1 = fma(e.y, breg[k + 1], a1);
+                        b0 = fma(u.x, breg[k], b0); b1 = fma(u.y, breg[k + 1], b1);
+                        q0 = fma(v.x, breg[k], q0); q1 = fma(v.y, breg[k + 1], q1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double s0 = a0 + a1;
+                    double ri = __builtin_amdgcn_rcp(s0);       // two Newton steps: ~1 ulp (a sufficient condition's input, 1e-9 allowance)
+                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
+                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
+                    const double m1 = (b0 + b1) * ri, m2 = (q0 + q1) * ri;
+                    const bool in = wreg < Nd;
+                    d1 = in ? cw * m1 : 0.0;
+                    d2 = in ? cw * (m2 - m1 * m1) : 0.0;
+                }
+                const int kp2 = KP >> 1;
+                for (int vb = 0; vb < NdL; vb += WAVE) {
+                    const int va = vb + lane, ia = va < NdL ? va : NdL - 1;
+                    const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll 5
+                    for (int kk = 0; kk < kp2; ++kk) {
+                        const double2 e = se2[kk], u = sv2[kk], v = sw2[kk], ba = ra[kk];
+                        a0 = fma(e.x, ba.x, a0); a1 = fma(e.y, ba.y, a1);
+                        b0 = fma(u.x, ba.x, b0); b1 = fma(u.y, ba.y, b1);
+                        q0 = fma(v.x, ba.x, q0); q1 = fma(v.y, ba.y, q1);
+                    }
+                    const double s0 = a0 + a1, m1 = (b0 + b1) / s0, m2 = (q0 + q1) / s0;
+                    const bool in = va < NdL;
+                    d1 += in ? crow[ia] * m1 : 0.0;
+                    d2 += in ? crow[ia] * (m2 - m1 * m1) : 0.0;
+                }
+            }
         };
         // the whole of f on one wave (NW = 1)
         auto eval_F = [&]() __attribute__((always_inline)) -> double {
@@ -974,6 +1035,17 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     if (cmd & 8) {   // its half of a BFGS matrix update (s, w in sv / sw; rho, cc in the mailbox)
                         if (lane < n) bfgs_rows(lane, nh < n ? nh : n, n, (cmd & 16) != 0, uni(xch_res[6]), uni(xch_res[7]), sv[lane], sw[lane]);
                         __syncthreads();  // (u) update complete
+                        continue;
+                    }
+                    if (cmd & 32) {  // moment pass along p (in the mailbox): this wave's words, g0 . p, p^T siginv p
+                        const double pl = (lane < n) ? xch_xt[lane] : 0.0;
+                        const double g0p = wave_sum(g0[0] * pl);
+                        const double qd = quad_of([&](int) __attribute__((always_inline)) -> double { return pl; });
+                        double d1, d2;
+                        moments_words(d1, d2, NdL);
+                        d1 = wave_sum(d1); d2 = wave_sum(d2);
+                        if (lane == 0) { xch_res[0] = d1; xch_res[1] = d2; xch_res[3] = g0p; xch_res[4] = qd; }
+                        __syncthreads();  // (m) moments posted
                         continue;
                     }
                     xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
@@ -1118,6 +1190,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // evaluation request / result + scipy ScalarFunction's last-x cache
         STM_UD(ss, alpha); STM_UD(ss, fval); STM_UD(ss, dval); STM_UD(ss, cache_f);
         bool want_eval = true, need_f = true, need_g = true;
+        STM_UD(ss, mvar0); STM_UD(ss, mD1); STM_UD(ss, mD2); STM_UD(ss, mg0p); STM_UD(ss, mqx);   // moment pass (S_MOMENTS)
+        bool want_mom = false;
         bool have_x = false, f_ok = false, g_ok = false;
         int st = S_INIT_DONE;
         // Second outcome-preserving test for a failing search, on the objective itself.  f along the ray has
@@ -1140,12 +1214,22 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         };
 
         if (P.debug_flags & 1) st = S_FINISH;
-        const bool cuts = !(P.debug_flags & 2), reuse = !(P.debug_flags & 4);
+        const bool cuts = !(P.debug_flags & 2), reuse = !(P.debug_flags & 4), mproof = !(P.debug_flags & 16);
         long guard = 0;
         if (P.prof) t_init = (long long)__builtin_readcyclecounter() - t_begin;
         while (st != S_FINISH) {
             if (++guard > 400000L) { status = 1000 + st; break; }
             const long long tq0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            if (NW == 2 && want_mom) {   // the moment pass requested by S_OUTER_TOP (operands in se / sv / sw and the mailbox)
+                if (lane == 0) xch_cmd[0] = 32;
+                __syncthreads();   // (0) wave 1: its words, g0 . p, p^T siginv p
+                double d1, d2;
+                moments_words(d1, d2, 0);
+                d1 = wave_sum(d1); d2 = wave_sum(d2);
+                __syncthreads();   // (m)
+                mD1 = d1 + uni(xch_res[0]); mD2 = py_max2(0.0, d2 + uni(xch_res[1])); mg0p = uni(xch_res[3]); mqx = uni(xch_res[4]);
+                want_mom = false;
+            }
             if (want_eval) {
                 // xk + alpha * pk (separate multiply and add, like numpy)
                 double xn[VPL];
@@ -1241,12 +1325,76 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     const double var0 = (wave_sum(v2) + eK * (c * c)) / Z;
                     const double quad = sdiag ? wave_sum(psp) : sig_lmax * pp;
                     Lv = (quad + Ndoc * var0) * (1.0 + 1e-9);
+                    // Third outcome-preserving test, before the first search spends an evaluation (k = 0: p = -df(x0), x0 the warm
+                    // start left by the previous EM iteration).  The reference's df is not the gradient of f, and from EM iteration 4 on
+                    // more than half of the documents start where f increases (or dips by 1e-4 and then increases) along p: every trial
+                    // step is rejected, DCSRCH and zoom bisect towards 0 until they give up -> status 2, x unchanged.  Along the ray
+                    //   f(s) = Q(s) + N_d lse(eta~ + s p~) - D(s),  D(s) = sum_w c_w log sum_k beta_d[k, w] exp(eta~_k + s p~_k),
+                    // Q is exactly quadratic, and the tilted distributions obey theta_s(i) >= e^{-s r} theta_0(i) and
+                    // q_{w,s}(i) <= e^{s r} q_{w,0}(i), r = range of p~ = [p, 0]; a variance is the minimum over a of E[(p~ - a)^2], hence
+                    //   Var_{theta_s}(p~) >= e^{-s r} var0,   D''(s) = sum_w c_w Var_{q_{w,s}}(p~) <= e^{s r} D2,   D2 = D''(0),
+                    //   f'(s) - c1 phi'(0) >= a0 + s p^T siginv p + N_d var0 (1 - e^{-s r}) / r - D2 (e^{s r} - 1) / r =: h(s),
+                    //   a0 = f'(0) + c1 |phi'(0)| with the TRUE slope f'(0) = phi'(0) + g0 . p - D1, D1 = D'(0) (df's data term is the constant g0),
+                    // so f(s) - [f(0) + c1 s phi'(0)] >= H(s) = int_0^s h.  h is concave (h'' <= 0).
+                    // (1) For s < s_x = 0.09 |phi'(0)| / U' (U' >= phi'' on [0, s_x], Lb / Lv as above) the curvature test
+                    //     |phi'(s)| <= 0.9 |phi'(0)| is out of reach: |phi'(s)| >= 0.91 |phi'(0)| (the dot product's rounding is 1e-13 of it).
+                    // (2) If h(s_x) > 0, H rises and then at most falls on [s_x, b], so H >= min(H(s_x), H(b)) there; when that exceeds the
+                    //     rounding of f (1e-9 max(1, |f|), as in armijo_dead) the sufficient-decrease test fails on all of [s_x, b].
+                    // b = the first trial step of DCSRCH and of wolfe2 (the same number): it is rejected by (2), which brackets [0, b], and
+                    // every later step of either search lies in (0, b) (S_W1_ITER's comment).  DCSRCH and _zoom accept a step only when
+                    // both tests hold -- nowhere on (0, b].  Every quantity is bounded in the safe direction (polynomial bounds of
+                    // the exponentials where their differences would cancel) and carries a 1e-9 relative allowance; NaNs fail the comparisons.
+                    // D1 and D2 cost one pass over beta_d with three sums per word instead of one (moments_words) and no logarithm.
+                    if (NW == 2 && cuts && mproof && k == 0 && derphi0 < 0.0 && range > 0.0) {
+                        // the pass runs at the loop's evaluation site (like an evaluation, nothing of this block is live across it);
+                        // its operands go through the LDS
+                        const double el = (lane < n) ? e[0] : (lane == n ? eK : 0.0), pl = (lane < n) ? p[0] : 0.0;
+                        se[lane] = el; sv[lane] = el * pl; sw[lane] = (el * pl) * pl;
+                        if (lane < n) xch_xt[lane] = pl;
+                        mvar0 = var0;
+                        want_mom = true;
+                    }
                 }
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
                 st = S_W1_START;
+                if (NW == 2 && want_mom) { st = S_MOMENTS; break; }
             } [[fallthrough]];
+            case S_MOMENTS:
             case S_W1_START: {  // scalar_search_wolfe1 + DCSRCH START
+                if (NW == 2 && st == S_MOMENTS) {   // the verdict of the moment pass (see S_OUTER_TOP)
+                    double b = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
+                    if (b < 0) b = 1.0;
+                    const double range = prange, D2 = mD2, qx = mqx, g0p = mg0p, D1 = mD1;
+                    const double slope0 = -derphi0, nv = Ndoc * mvar0;
+                    const double a0 = ((derphi0 + g0p) - D1) + c1 * slope0, a0tol = 1e-9 * (slope0 + fabs(g0p) + fabs(D1));
+                    const double s0 = 0.09 * slope0 / Lv, t0 = s0 * range;
+                    const double Ux = (t0 <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + t0 + t0 * t0)) : (double)Lb;
+                    const double sx = 0.09 * slope0 / Ux;
+                    // lower bounds of h(s) and H(s)
+                    auto hH = [&](double sq, double &h_out, double &H_out) __attribute__((always_inline)) {
+                        const double t = sq * range, et = exp(t), eti = 1.0 / et;
+                        const bool small = t < 0.05;
+                        const double A = small ? t - 0.5 * t * t : 1.0 - eti;                                   // <= 1 - e^-t
+                        const double B = small ? t + 0.5 * t * t * et : et - 1.0;                             // >= e^t - 1
+                        const double C = small ? t * t * (0.5 - t * (1.0 / 6.0)) : (t - 1.0) + eti;           // <= t - 1 + e^-t
+                        const double E = small ? t * t * (0.5 + t * (1.0 / 6.0) * et) : (et - 1.0) - t;       // >= e^t - 1 - t
+                        const double up1 = nv * (A / range), dn1 = D2 * (B / range);
+                        const double up2 = nv * (C / (range * range)), dn2 = D2 * (E / (range * range));
+                        h_out = (a0 + qx * sq + up1 - dn1) - (a0tol + 1e-9 * (qx * sq + up1 + dn1));
+                        H_out = (a0 * sq + 0.5 * qx * sq * sq + up2 - dn2) - (a0tol * sq + 1e-9 * (0.5 * qx * sq * sq + up2 + dn2));
+                    };
+                    bool dead = false;
+                    if (finite_d(b) && b > 0.0 && qx >= 0.0 && Ux > 0.0 && sx > 0.0) {
+                        const double fm = 1e-9 * py_max2(1.0, fabs((double)phi0));
+                        double hx, Hx, hb, Hb;
+                        hH(py_min2(sx, b), hx, Hx);
+                        hH(b, hb, Hb);
+                        dead = Hb >= fm && (sx >= b || (hx > 0.0 && Hx >= fm));   // (b itself has to be rejected: that is what brackets)
+                    }
+                    if (dead) { status = 2; st = S_FINISH; break; }
+                    st = S_W1_START;
+                }
                 double a1;
                 w1_have = false;
                 if (derphi0 != 0) {
