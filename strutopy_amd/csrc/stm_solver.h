@@ -29,7 +29,7 @@
 #define STM_EVAL_GROUP 8   // topics per scheduling group of the evaluation's register pass
 #endif
 #ifndef STM_MOM_GROUP
-#define STM_MOM_GROUP 2    // ... of the moment pass (three broadcast vectors, six sums)
+#define STM_MOM_GROUP 8    // ... of the moment pass (three broadcast vectors, six sums)
 #endif
 
 namespace stm {
@@ -75,8 +75,8 @@ struct SolverParams {
 
 enum : int {
     S_INIT_DONE = 0, S_OUTER_TOP, S_W1_START, S_W1_ITER, S_W2_START, S_W2_FIRST, S_W2_TOP,
-    S_W2_GOT_G, S_W2_GOT_F, S_ZOOM_TOP, S_ZOOM_GOT_F, S_ZOOM_GOT_G, S_ZOOM_NEXT, S_ACCEPT,
-    S_ACCEPT2, S_FINISH, S_MOMENTS   // (S_MOMENTS last: the profile slots of the other states keep their numbers)
+    S_W2_GOT_G, S_W2_GOT_F, S_ZOOM_TOP, S_ZOOM_GOT_F, S_ZOOM_GOT_G, S_MOMENTS, S_ACCEPT,
+    S_ACCEPT2, S_FINISH
 };
 
 // scipy/optimize/_dcsrch.py:502-728 dcstep (wave-uniform scalars).  State in and out BY VALUE and
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             return part;
         };
         // d^T siginv d, wave-summed; dv(r) = the lane's component lane + 64 r of d
-        auto quad_of = [&](auto dv) __attribute__((always_inline)) -> double {
+        auto quad_of = [&](auto dv, double *svx) __attribute__((always_inline)) -> double {   // svx: the wave's broadcast vector (dense siginv)
             double q = 0.0;
             if (sdiag) {
 #pragma unroll
@@ -898,19 +898,28 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         };
         // (eta - mu)^T siginv (eta - mu)
         auto quad_F = [&]() __attribute__((always_inline)) -> double {
-            return quad_of([&](int r) __attribute__((always_inline)) -> double { return xt[r] - mu[r]; });
+            return quad_of([&](int r) __attribute__((always_inline)) -> double { return xt[r] - mu[r]; }, svx);
         };
         // Moment pass of the two-wave form (see S_OUTER_TOP): with e = exp(eta~ - m) in se[], e p~ in sv[] and e p~^2 in sw[],
         // the mean and the variance of p~ under q_w(k) ~ beta_d[k, w] e_k for each of this wave's words, summed with the word
         // counts: d1 = sum_w c_w E_{q_w}[p~] (the derivative of f's data term along p), d2 = sum_w c_w Var_{q_w}(p~) (its
         // second derivative).  Per lane; the caller wave-sums.  Feeds a sufficient condition only -- nothing scipy computes.
+        constexpr bool MOM = !GLOBAL_SLAB;   // forms with a moment pass (the HBM-slab fallback keeps the cuts of rounds 1-2)
         auto moments_words = [&](double &d1, double &d2, const int NdL) __attribute__((always_inline)) {
             d1 = 0.0; d2 = 0.0;
-            if constexpr (NW == 2) {
+            if constexpr (MOM) {
                 const double2 *se2 = reinterpret_cast<const double2 *>(se);
                 const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
                 const double2 *sw2 = reinterpret_cast<const double2 *>(sw);
-                {
+                // mean and variance from the three sums (reciprocal by two Newton steps: ~1 ulp; a sufficient condition's input)
+                auto mv = [&](double s0, double s1, double s2, double &m1, double &var) __attribute__((always_inline)) {
+                    double ri = __builtin_amdgcn_rcp(s0);
+                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
+                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
+                    m1 = s1 * ri;
+                    var = s2 * ri - m1 * m1;
+                };
+                if constexpr (KREG > 0) {
                     // the word's count again from memory (L2): a second use of c0 at this site costs 225 spilled registers
                     const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;
                     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
@@ -923,31 +932,59 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         q0 = fma(v.x, breg[k], q0); q1 = fma(v.y, breg[k + 1], q1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    const double s0 = a0 + a1;
-                    double ri = __builtin_amdgcn_rcp(s0);       // two Newton steps: ~1 ulp (a sufficient condition's input, 1e-9 allowance)
-                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
-                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
-                    const double m1 = (b0 + b1) * ri, m2 = (q0 + q1) * ri;
+                    double m1, var;
+                    mv(a0 + a1, b0 + b1, q0 + q1, m1, var);
                     const bool in = wreg < Nd;
                     d1 = in ? cw * m1 : 0.0;
-                    d2 = in ? cw * (m2 - m1 * m1) : 0.0;
+                    d2 = in ? cw * var : 0.0;
                 }
-                const int kp2 = KP >> 1;
-                for (int vb = 0; vb < NdL; vb += WAVE) {
-                    const int va = vb + lane, ia = va < NdL ? va : NdL - 1;
-                    const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
-                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
-#pragma unroll 5
-                    for (int kk = 0; kk < kp2; ++kk) {
-                        const double2 e = se2[kk], u = sv2[kk], v = sw2[kk], ba = ra[kk];
-                        a0 = fma(e.x, ba.x, a0); a1 = fma(e.y, ba.y, a1);
-                        b0 = fma(u.x, ba.x, b0); b1 = fma(u.y, ba.y, b1);
-                        q0 = fma(v.x, ba.x, q0); q1 = fma(v.y, ba.y, q1);
+                if constexpr (DIRECT) {   // tile by tile, lane = (word, quarter of the topics), as data_F
+                    tile_fetch(0);
+                    const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
+                    for (int t0 = 0; t0 < NdL; t0 += TWS) {
+                        const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
+                        tile_store();
+                        STM_WAVE_SYNC();
+                        if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
+                        const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);
+                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll 2
+                        for (int kk = k0; kk < k1; ++kk) {
+                            const double2 e = se2[kk], u = sv2[kk], v = sw2[kk], bb = tr[kk];
+                            a0 = fma(e.x, bb.x, a0); a1 = fma(e.y, bb.y, a1);
+                            b0 = fma(u.x, bb.x, b0); b1 = fma(u.y, bb.y, b1);
+                            q0 = fma(v.x, bb.x, q0); q1 = fma(v.y, bb.y, q1);
+                        }
+                        double s0 = a0 + a1, s1 = b0 + b1, s2 = q0 + q1;
+                        s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                        s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                        double m1, var;
+                        mv(s0, s1, s2, m1, var);
+                        const bool in = dq == 0 && dw < nw;
+                        const double cw = crow[t0 + (dw < nw ? dw : 0)];
+                        d1 += in ? cw * m1 : 0.0;
+                        d2 += in ? cw * var : 0.0;
+                        STM_WAVE_SYNC();
                     }
-                    const double s0 = a0 + a1, m1 = (b0 + b1) / s0, m2 = (q0 + q1) / s0;
-                    const bool in = va < NdL;
-                    d1 += in ? crow[ia] * m1 : 0.0;
-                    d2 += in ? crow[ia] * (m2 - m1 * m1) : 0.0;
+                } else {
+                    const int kp2 = KP >> 1;
+                    for (int vb = 0; vb < NdL; vb += WAVE) {
+                        const int va = vb + lane, ia = va < NdL ? va : NdL - 1;
+                        const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll 5
+                        for (int kk = 0; kk < kp2; ++kk) {
+                            const double2 e = se2[kk], u = sv2[kk], v = sw2[kk], ba = ra[kk];
+                            a0 = fma(e.x, ba.x, a0); a1 = fma(e.y, ba.y, a1);
+                            b0 = fma(u.x, ba.x, b0); b1 = fma(u.y, ba.y, b1);
+                            q0 = fma(v.x, ba.x, q0); q1 = fma(v.y, ba.y, q1);
+                        }
+                        double m1, var;
+                        mv(a0 + a1, b0 + b1, q0 + q1, m1, var);
+                        const bool in = va < NdL;
+                        d1 += in ? crow[ia] * m1 : 0.0;
+                        d2 += in ? crow[ia] * var : 0.0;
+                    }
                 }
             }
         };
@@ -1040,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     if (cmd & 32) {  // moment pass along p (in the mailbox): this wave's words, g0 . p, p^T siginv p
                         const double pl = (lane < n) ? xch_xt[lane] : 0.0;
                         const double g0p = wave_sum(g0[0] * pl);
-                        const double qd = quad_of([&](int) __attribute__((always_inline)) -> double { return pl; });
+                        const double qd = quad_of([&](int) __attribute__((always_inline)) -> double { return pl; }, svx);
                         double d1, d2;
                         moments_words(d1, d2, NdL);
                         d1 = wave_sum(d1); d2 = wave_sum(d2);
@@ -1220,14 +1257,19 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         while (st != S_FINISH) {
             if (++guard > 400000L) { status = 1000 + st; break; }
             const long long tq0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-            if (NW == 2 && want_mom) {   // the moment pass requested by S_OUTER_TOP (operands in se / sv / sw and the mailbox)
-                if (lane == 0) xch_cmd[0] = 32;
-                __syncthreads();   // (0) wave 1: its words, g0 . p, p^T siginv p
+            if (MOM && want_mom) {   // the moment pass requested by S_OUTER_TOP (operands in se / sv / sw; two-wave form: p in the mailbox)
                 double d1, d2;
-                moments_words(d1, d2, 0);
-                d1 = wave_sum(d1); d2 = wave_sum(d2);
-                __syncthreads();   // (m)
-                mD1 = d1 + uni(xch_res[0]); mD2 = py_max2(0.0, d2 + uni(xch_res[1])); mg0p = uni(xch_res[3]); mqx = uni(xch_res[4]);
+                if (NW == 2) {
+                    if (lane == 0) xch_cmd[0] = 32;
+                    __syncthreads();   // (0) wave 1: its words, g0 . p, p^T siginv p (on wave 0 the quadratic form measured slower)
+                    moments_words(d1, d2, 0);
+                    d1 = wave_sum(d1); d2 = wave_sum(d2);
+                    __syncthreads();   // (m)
+                    mD1 = d1 + uni(xch_res[0]); mD2 = py_max2(0.0, d2 + uni(xch_res[1])); mg0p = uni(xch_res[3]); mqx = uni(xch_res[4]);
+                } else {
+                    moments_words(d1, d2, NdL);
+                    mD1 = wave_sum(d1); mD2 = py_max2(0.0, wave_sum(d2)); mg0p = dot(g0, p);   // (mqx: S_OUTER_TOP)
+                }
                 want_mom = false;
             }
             if (want_eval) {
@@ -1345,12 +1387,18 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     // both tests hold -- nowhere on (0, b].  Every quantity is bounded in the safe direction (polynomial bounds of
                     // the exponentials where their differences would cancel) and carries a 1e-9 relative allowance; NaNs fail the comparisons.
                     // D1 and D2 cost one pass over beta_d with three sums per word instead of one (moments_words) and no logarithm.
-                    if (NW == 2 && cuts && mproof && k == 0 && derphi0 < 0.0 && range > 0.0) {
+                    if (MOM && cuts && mproof && k == 0 && derphi0 < 0.0 && range > 0.0) {
                         // the pass runs at the loop's evaluation site (like an evaluation, nothing of this block is live across it);
                         // its operands go through the LDS
-                        const double el = (lane < n) ? e[0] : (lane == n ? eK : 0.0), pl = (lane < n) ? p[0] : 0.0;
-                        se[lane] = el; sv[lane] = el * pl; sw[lane] = (el * pl) * pl;
-                        if (lane < n) xch_xt[lane] = pl;
+                        if (NW == 1) mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);   // (before sv is an operand)
+#pragma unroll
+                        for (int r = 0; r < VPL; ++r) {
+                            const int i = lane + WAVE * r;
+                            const double el = (i < n) ? e[r] : (i == n ? eK : 0.0), pl = (i < n) ? p[r] : 0.0;
+                            se[i] = el; sv[i] = el * pl; sw[i] = (el * pl) * pl;
+                            if (NW == 2 && i < n) xch_xt[i] = pl;
+                        }
+                        if (NW == 1) STM_WAVE_SYNC();
                         mvar0 = var0;
                         want_mom = true;
                     }
@@ -1358,39 +1406,45 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
                 st = S_W1_START;
-                if (NW == 2 && want_mom) { st = S_MOMENTS; break; }
+                if (MOM && want_mom) { st = S_MOMENTS; break; }
             } [[fallthrough]];
             case S_MOMENTS:
             case S_W1_START: {  // scalar_search_wolfe1 + DCSRCH START
-                if (NW == 2 && st == S_MOMENTS) {   // the verdict of the moment pass (see S_OUTER_TOP)
+                if (MOM && st == S_MOMENTS) {   // the verdict of the moment pass (see S_OUTER_TOP)
                     double b = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
                     if (b < 0) b = 1.0;
                     const double range = prange, D2 = mD2, qx = mqx, g0p = mg0p, D1 = mD1;
                     const double slope0 = -derphi0, nv = Ndoc * mvar0;
                     const double a0 = ((derphi0 + g0p) - D1) + c1 * slope0, a0tol = 1e-9 * (slope0 + fabs(g0p) + fabs(D1));
-                    const double s0 = 0.09 * slope0 / Lv, t0 = s0 * range;
-                    const double Ux = (t0 <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + t0 + t0 * t0)) : (double)Lb;
-                    const double sx = 0.09 * slope0 / Ux;
-                    // lower bounds of h(s) and H(s)
-                    auto hH = [&](double sq, double &h_out, double &H_out) __attribute__((always_inline)) {
-                        const double t = sq * range, et = exp(t), eti = 1.0 / et;
-                        const bool small = t < 0.05;
-                        const double A = small ? t - 0.5 * t * t : 1.0 - eti;                                   // <= 1 - e^-t
-                        const double B = small ? t + 0.5 * t * t * et : et - 1.0;                             // >= e^t - 1
-                        const double C = small ? t * t * (0.5 - t * (1.0 / 6.0)) : (t - 1.0) + eti;           // <= t - 1 + e^-t
-                        const double E = small ? t * t * (0.5 + t * (1.0 / 6.0) * et) : (et - 1.0) - t;       // >= e^t - 1 - t
-                        const double up1 = nv * (A / range), dn1 = D2 * (B / range);
-                        const double up2 = nv * (C / (range * range)), dn2 = D2 * (E / (range * range));
-                        h_out = (a0 + qx * sq + up1 - dn1) - (a0tol + 1e-9 * (qx * sq + up1 + dn1));
-                        H_out = (a0 * sq + 0.5 * qx * sq * sq + up2 - dn2) - (a0tol * sq + 1e-9 * (0.5 * qx * sq * sq + up2 + dn2));
-                    };
                     bool dead = false;
-                    if (finite_d(b) && b > 0.0 && qx >= 0.0 && Ux > 0.0 && sx > 0.0) {
-                        const double fm = 1e-9 * py_max2(1.0, fabs((double)phi0));
+                    // h <= a0 + s (p^T siginv p + N_d var0): two out of five documents leave here (f falls along p)
+                    if (finite_d(b) && b > 0.0 && qx >= 0.0 && a0 + b * (qx + nv) > 0.0) {
+                        const double s0 = 0.09 * slope0 / Lv, t0 = s0 * range;
+                        const double Ux = (t0 <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + t0 + t0 * t0)) : (double)Lb;
+                        const double sx = py_min2(0.09 * slope0 / Ux, b);
+                        const double ir = 1.0 / range, fm = 1e-9 * py_max2(1.0, fabs((double)phi0));
+                        // lower bounds of h(s) and H(s) (reciprocals instead of quotients: inside the 1e-9 allowance)
+                        auto hH = [&](double sq, double &h_out, double &H_out) __attribute__((always_inline)) {
+                            const double t = sq * range, et = exp(t), eti = 1.0 / et;
+                            const bool small = t < 0.05;
+                            const double A = small ? t - 0.5 * t * t : 1.0 - eti;                                   // <= 1 - e^-t
+                            const double B = small ? t + 0.5 * t * t * et : et - 1.0;                             // >= e^t - 1
+                            const double C = small ? t * t * (0.5 - t * (1.0 / 6.0)) : (t - 1.0) + eti;           // <= t - 1 + e^-t
+                            const double E = small ? t * t * (0.5 + t * (1.0 / 6.0) * et) : (et - 1.0) - t;       // >= e^t - 1 - t
+                            const double up1 = nv * (A * ir), dn1 = D2 * (B * ir);
+                            const double up2 = nv * ((C * ir) * ir), dn2 = D2 * ((E * ir) * ir);
+                            h_out = (a0 + qx * sq + up1 - dn1) - (a0tol + 1e-9 * (qx * sq + up1 + dn1));
+                            H_out = (a0 * sq + 0.5 * qx * sq * sq + up2 - dn2) - (a0tol * sq + 1e-9 * (0.5 * qx * sq * sq + up2 + dn2));
+                        };
                         double hx, Hx, hb, Hb;
-                        hH(py_min2(sx, b), hx, Hx);
                         hH(b, hb, Hb);
-                        dead = Hb >= fm && (sx >= b || (hx > 0.0 && Hx >= fm));   // (b itself has to be rejected: that is what brackets)
+                        if (Ux > 0.0 && sx > 0.0 && Hb >= fm) {   // (b itself has to be rejected: that is what brackets)
+                            if (sx >= b) dead = true;
+                            else {
+                                hH(sx, hx, Hx);
+                                dead = hx > 0.0 && Hx >= fm;
+                            }
+                        }
                     }
                     if (dead) { status = 2; st = S_FINISH; break; }
                     st = S_W1_START;
@@ -1575,7 +1629,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 const double phi_aj = fval;
                 if (phi_aj > phi0 + c1 * a_j * derphi0 || phi_aj >= phi_lo) {
                     phi_rec = phi_hi; a_rec = a_hi; a_hi = a_j; phi_hi = phi_aj;
-                    ++zi;   // S_ZOOM_NEXT, inlined
+                    ++zi;
                     if (zi > 10) { status = 2; st = S_FINISH; break; }
                     st = S_ZOOM_TOP;
                     break;
@@ -1597,11 +1651,6 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     phi_rec = phi_lo; a_rec = a_lo;
                 }
                 a_lo = a_j; phi_lo = phi_aj; derphi_lo = derphi_aj;
-                ++zi;   // S_ZOOM_NEXT, inlined
-                if (zi > 10) { status = 2; st = S_FINISH; break; }
-                st = S_ZOOM_TOP;
-            } break;
-            case S_ZOOM_NEXT: {
                 ++zi;
                 if (zi > 10) { status = 2; st = S_FINISH; break; }
                 st = S_ZOOM_TOP;

@@ -113,12 +113,13 @@ def test_content_levels_full_iteration_at_k50(oracle):
 
 
 # ------------------------------------------------------------------ K=50, later EM iterations, teacher-forced
-@pytest.mark.parametrize("flags", ["0", "6"])
+@pytest.mark.parametrize("flags", ["0", "16", "6"])
 def test_k50_later_iterations_teacher_forced(oracle, monkeypatch, flags):
     """tests/golden/k50_late.npz: the reference's EM iterations 3, 4, 5 and 8 at K=50 / V=10k (2000 documents) with the
     complete input state of each E-step.  From iteration 4 on about half of the documents take BFGS steps that move; the
-    HIP solver must follow scipy exactly there.  STM_DEBUG_FLAGS=6 disables the outcome-preserving line-search cuts:
-    both builds must agree with the reference AND with each other (the cuts change nothing)."""
+    HIP solver must follow scipy exactly there.  STM_DEBUG_FLAGS=6 disables the outcome-preserving line-search cuts,
+    16 only the moment pass in front of the first search (round 3): all three must agree with the reference AND
+    with each other (the cuts change nothing)."""
     from strutopy_amd.engine import estep_host
     monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
     g = load_golden("k50_late")
@@ -141,6 +142,30 @@ def test_k50_later_iterations_teacher_forced(oracle, monkeypatch, flags):
             o = oracle.estep(*args, nthreads=0)
             assert np.array_equal(o["status"], g[p + "status"]) and np.array_equal(o["nit"], g[p + "nit"])
             assert np.max(np.abs(d["eta"] - o["eta"])) <= 1e-7
+
+
+def test_moment_pass_proves_failing_first_searches(monkeypatch):
+    """The moment pass (stm_solver.h, S_MOMENTS) must actually fire: at the reference's EM iteration 8 (k50_late) 44 % of
+    the documents end in a first line search that cannot succeed; with the pass they finish after one evaluation and one
+    pass over beta_d, without it after 5-6 evaluations.  Same status / nit / eta bit for bit (x is left unchanged either way)."""
+    from strutopy_amd.engine import estep_host
+    g = load_golden("k50_late")
+    p = "it8_"
+    args = (g["indptr"], g["indices"], g["counts"], g[p + "beta_in"], g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+            float(g[p + "sigmaentropy"]))
+    out = {}
+    for flags in ("0", "16"):
+        monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
+        out[flags] = estep_host(*args)
+    a, b = out["0"], out["16"]
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["nit"], b["nit"])
+    assert np.array_equal(a["eta"], b["eta"])
+    still = a["nit"] == 0
+    assert still.mean() > 0.3
+    # documents that do not move: one evaluation (plus the reused / skipped ones scipy would count) against 5-6
+    assert a["nfev"][still].mean() <= 0.45 * b["nfev"][still].mean()
+    assert np.array_equal(a["nfev"][~still], b["nfev"][~still]) or a["nfev"][~still].mean() <= b["nfev"][~still].mean()
+
 
 
 def _against_reference(d, g, p, tag):

@@ -28,7 +28,7 @@ for it in range(ITS):
     print("   solver set-up cycles/doc (wave 0): gather %.0f, word-count exchange %.0f, lane vectors + g0 %.0f; wave 1 gather incl. slab %.0f" % tuple(out[:, 4:8].mean(0)))
     print("   one evaluation on wave 0, cycles/doc: post + barrier 0 %.0f, max/exp %.0f, barrier 1 %.0f, lse + data term %.0f, barrier 2 %.0f" % tuple(out[:, 40:45].mean(0)))
     names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
-             "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "ZOOM_NEXT", "ACCEPT", "ACCEPT2", "FINISH"]
+             "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "MOMENTS", "ACCEPT", "ACCEPT2", "FINISH"]
     pn = ["prologue", "word tiles", "H assembly", "Cholesky ladder", "bound", "inverse", "nu"]
     print("   post kernel cycles/doc: " + ", ".join(f"{pn[q]} {out[:, 32 + q].mean():.0f}" for q in range(7)) + f", total {out[:, 32:39].sum(1).mean():.0f}")
     if True:
