@@ -905,20 +905,71 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // counts: d1 = sum_w c_w E_{q_w}[p~] (the derivative of f's data term along p), d2 = sum_w c_w Var_{q_w}(p~) (its
         // second derivative).  Per lane; the caller wave-sums.  Feeds a sufficient condition only -- nothing scipy computes.
         constexpr bool MOM = !GLOBAL_SLAB;   // forms with a moment pass (the HBM-slab fallback keeps the cuts of rounds 1-2)
-        auto moments_words = [&](double &d1, double &d2, const int NdL) __attribute__((always_inline)) {
-            d1 = 0.0; d2 = 0.0;
-            if constexpr (MOM) {
+        // mean and variance from the three sums (reciprocal by two Newton steps: ~1 ulp; a sufficient condition's input)
+        auto mv = [&](double s0, double s1, double s2, double &m1, double &var) __attribute__((always_inline)) {
+            double ri = __builtin_amdgcn_rcp(s0);
+            ri = fma(fma(-s0, ri, 1.0), ri, ri);
+            ri = fma(fma(-s0, ri, 1.0), ri, ri);
+            m1 = s1 * ri;
+            var = s2 * ri - m1 * m1;
+        };
+        // Two-wave form: the FIRST evaluation and the moment pass in one sweep over beta_d (p = -df(x0) is known before f's data
+        // term is: df needs no beta_d).  The sums of exp(eta~ - m) beta_d are data_F's, chain for chain, so f(x0) has the bits of
+        // the plain evaluation; the two extra sums per word ride on the same register / LDS reads.
+        auto words_F3 = [&](double m, const int NdL, double &part, double &d1, double &d2) __attribute__((always_inline)) {
+            part = 0.0; d1 = 0.0; d2 = 0.0;
+            if constexpr (NW == 2) {
                 const double2 *se2 = reinterpret_cast<const double2 *>(se);
                 const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
                 const double2 *sw2 = reinterpret_cast<const double2 *>(sw);
-                // mean and variance from the three sums (reciprocal by two Newton steps: ~1 ulp; a sufficient condition's input)
-                auto mv = [&](double s0, double s1, double s2, double &m1, double &var) __attribute__((always_inline)) {
-                    double ri = __builtin_amdgcn_rcp(s0);
-                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
-                    ri = fma(fma(-s0, ri, 1.0), ri, ri);
-                    m1 = s1 * ri;
-                    var = s2 * ri - m1 * m1;
-                };
+                {
+                    const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;   // (= c0; see moments_words)
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KR; k += 2) {
+                        if (k % STM_MOM_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+                        const double2 e = se2[k / 2], u = sv2[k / 2], v = sw2[k / 2];
+                        a0 = fma(e.x, breg[k], a0); a1 = fma(e.y, breg[k + 1], a1);
+                        b0 = fma(u.x, breg[k], b0); b1 = fma(u.y, breg[k + 1], b1);
+                        q0 = fma(v.x, breg[k], q0); q1 = fma(v.y, breg[k + 1], q1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double s0 = a0 + a1, lg = m + log_pos(s0);
+                    double m1, var;
+                    mv(s0, b0 + b1, q0 + q1, m1, var);
+                    const bool in = wreg < Nd;
+                    part = in ? cw * lg : 0.0;
+                    d1 = in ? cw * m1 : 0.0;
+                    d2 = in ? cw * var : 0.0;
+                }
+                const int kp2 = KP >> 1;
+                for (int vb = 0; vb < NdL; vb += WAVE) {
+                    const int va = vb + lane, ia = va < NdL ? va : NdL - 1;
+                    const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll 5
+                    for (int kk = 0; kk < kp2; ++kk) {
+                        const double2 e = se2[kk], u = sv2[kk], v = sw2[kk], ba = ra[kk];
+                        a0 = fma(e.x, ba.x, a0); a1 = fma(e.y, ba.y, a1);
+                        b0 = fma(u.x, ba.x, b0); b1 = fma(u.y, ba.y, b1);
+                        q0 = fma(v.x, ba.x, q0); q1 = fma(v.y, ba.y, q1);
+                    }
+                    const double s0 = a0 + a1, la = m + log_pos(s0);
+                    double m1, var;
+                    mv(s0, b0 + b1, q0 + q1, m1, var);
+                    const bool in = va < NdL;
+                    part += in ? crow[ia] * la : 0.0;
+                    d1 += in ? crow[ia] * m1 : 0.0;
+                    d2 += in ? crow[ia] * var : 0.0;
+                }
+            }
+        };
+        auto moments_words = [&](double &d1, double &d2, const int NdL) __attribute__((always_inline)) {
+            d1 = 0.0; d2 = 0.0;
+            if constexpr (MOM && NW == 1) {
+                const double2 *se2 = reinterpret_cast<const double2 *>(se);
+                const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
+                const double2 *sw2 = reinterpret_cast<const double2 *>(sw);
                 if constexpr (KREG > 0) {
                     // the word's count again from memory (L2): a second use of c0 at this site costs 225 spilled registers
                     const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;
@@ -1074,15 +1125,21 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         __syncthreads();  // (u) update complete
                         continue;
                     }
-                    if (cmd & 32) {  // moment pass along p (in the mailbox): this wave's words, g0 . p, p^T siginv p
-                        const double pl = (lane < n) ? xch_xt[lane] : 0.0;
+                    if (cmd & 64) {  // the first evaluation, fused with the moment pass along p = -df(x0) (words_F3)
+                        xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
+                        const double q = quad_F();
+                        eval_DF();
+                        if (lane < n) xch_gv[lane] = gv[0];
+                        __syncthreads();  // (1) df posted; exp(eta~ - m) in se[], m in xch_res[2]
+                        const double pl = -gv[0];   // (0 beyond n)
+                        __syncthreads();  // (1b) exp(eta~ - m) p~ and exp(eta~ - m) p~^2 in sv[] / sw[]
+                        double part, d1, d2;
+                        words_F3(uni(xch_res[2]), NdL, part, d1, d2);
+                        part = wave_sum(part); d1 = wave_sum(d1); d2 = wave_sum(d2);
                         const double g0p = wave_sum(g0[0] * pl);
                         const double qd = quad_of([&](int) __attribute__((always_inline)) -> double { return pl; }, svx);
-                        double d1, d2;
-                        moments_words(d1, d2, NdL);
-                        d1 = wave_sum(d1); d2 = wave_sum(d2);
-                        if (lane == 0) { xch_res[0] = d1; xch_res[1] = d2; xch_res[3] = g0p; xch_res[4] = qd; }
-                        __syncthreads();  // (m) moments posted
+                        if (lane == 0) { xch_res[0] = part; xch_res[1] = q; xch_res[3] = g0p; xch_res[4] = qd; xch_res[5] = d1; xch_res[6] = d2; }
+                        __syncthreads();  // (2) results posted
                         continue;
                     }
                     xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
@@ -1146,6 +1203,33 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 f_out = 0.5 * q - (part_all - Ndoc * lse);
             }
             if (do_g) gv[0] = (lane < n) ? xch_gv[lane] : 0.0;
+        };
+
+        // wave 0 of the two-wave form: f, df and the moments D1, D2, g0 . p, p^T siginv p at x0 (p = -df(x0): the first direction)
+        auto eval_first = [&](double &f_out, double &D1_out, double &D2_out, double &g0p_out, double &qx_out) __attribute__((always_inline)) {
+            double m = 0.0, ssum = 0.0, e_lane = 0.0;
+            int icnt = 1;
+            if (lane < n) xch_xt[lane] = xt[0];
+            if (lane == 0) xch_cmd[0] = 1 | 2 | 64;
+            __syncthreads();   // (0) wave 1: quadratic form and df
+            head_F(m, icnt, ssum, e_lane);
+            if (lane == 0) xch_res[2] = m;
+            const double lse = lse_F(m, icnt, ssum);
+            __syncthreads();   // (1)
+            gv[0] = (lane < n) ? xch_gv[lane] : 0.0;
+            {
+                const double pl = -gv[0], ep = e_lane * pl;   // e_lane: exp(eta~ - m) of topic `lane` (0 beyond K), p~ = 0 from n on
+                sv[lane] = ep; sw[lane] = ep * pl;
+            }
+            __syncthreads();   // (1b)
+            double part, d1, d2;
+            words_F3(m, 0, part, d1, d2);   // words 0..63 (wave 1 owns the slab)
+            part = wave_sum(part); d1 = wave_sum(d1); d2 = wave_sum(d2);
+            __syncthreads();   // (2)
+            const double part_all = part + uni(xch_res[0]);
+            const double q = uni(xch_res[1]);
+            f_out = 0.5 * q - (part_all - Ndoc * lse);
+            D1_out = d1 + uni(xch_res[5]); D2_out = py_max2(0.0, d2 + uni(xch_res[6])); g0p_out = uni(xch_res[3]); qx_out = uni(xch_res[4]);
         };
 
         auto dot = [&](const double (&a)[VPL], const double (&b)[VPL]) __attribute__((always_inline)) -> double {
@@ -1257,19 +1341,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         while (st != S_FINISH) {
             if (++guard > 400000L) { status = 1000 + st; break; }
             const long long tq0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-            if (MOM && want_mom) {   // the moment pass requested by S_OUTER_TOP (operands in se / sv / sw; two-wave form: p in the mailbox)
+            if (MOM && NW == 1 && want_mom) {   // one-wave forms: the moment pass requested by S_OUTER_TOP (operands in se / sv / sw)
                 double d1, d2;
-                if (NW == 2) {
-                    if (lane == 0) xch_cmd[0] = 32;
-                    __syncthreads();   // (0) wave 1: its words, g0 . p, p^T siginv p (on wave 0 the quadratic form measured slower)
-                    moments_words(d1, d2, 0);
-                    d1 = wave_sum(d1); d2 = wave_sum(d2);
-                    __syncthreads();   // (m)
-                    mD1 = d1 + uni(xch_res[0]); mD2 = py_max2(0.0, d2 + uni(xch_res[1])); mg0p = uni(xch_res[3]); mqx = uni(xch_res[4]);
-                } else {
-                    moments_words(d1, d2, NdL);
-                    mD1 = wave_sum(d1); mD2 = py_max2(0.0, wave_sum(d2)); mg0p = dot(g0, p);   // (mqx: S_OUTER_TOP)
-                }
+                moments_words(d1, d2, NdL);
+                mD1 = wave_sum(d1); mD2 = py_max2(0.0, wave_sum(d2)); mg0p = dot(g0, p);   // (mqx: S_OUTER_TOP)
                 want_mom = false;
             }
             if (want_eval) {
@@ -1287,7 +1362,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     for (int r = 0; r < VPL; ++r) xt[r] = xn[r];
                     have_x = true; f_ok = false; g_ok = false;
                 }
-                if (NW == 2) {
+                if (NW == 2 && st == S_INIT_DONE && cuts && mproof) {   // the first evaluation carries the moment pass
+                    double fnew = 0.0, D1 = 0.0, D2 = 0.0, g0p = 0.0, qx = 0.0;
+                    eval_first(fnew, D1, D2, g0p, qx);
+                    mD1 = D1; mD2 = D2; mg0p = g0p; mqx = qx;
+                    cache_f = fnew; f_ok = true; ++nfev; g_ok = true; ++njev;
+                    fval = cache_f; dval = 0.0;
+                } else if (NW == 2) {
                     const bool do_f = need_f && !f_ok, do_g = need_g && !g_ok;
                     if (do_f || do_g) {
                         double fnew = 0.0;
@@ -1388,25 +1469,30 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     // the exponentials where their differences would cancel) and carries a 1e-9 relative allowance; NaNs fail the comparisons.
                     // D1 and D2 cost one pass over beta_d with three sums per word instead of one (moments_words) and no logarithm.
                     if (MOM && cuts && mproof && k == 0 && derphi0 < 0.0 && range > 0.0) {
-                        // the pass runs at the loop's evaluation site (like an evaluation, nothing of this block is live across it);
-                        // its operands go through the LDS
-                        if (NW == 1) mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);   // (before sv is an operand)
-#pragma unroll
-                        for (int r = 0; r < VPL; ++r) {
-                            const int i = lane + WAVE * r;
-                            const double el = (i < n) ? e[r] : (i == n ? eK : 0.0), pl = (i < n) ? p[r] : 0.0;
-                            se[i] = el; sv[i] = el * pl; sw[i] = (el * pl) * pl;
-                            if (NW == 2 && i < n) xch_xt[i] = pl;
-                        }
-                        if (NW == 1) STM_WAVE_SYNC();
                         mvar0 = var0;
                         want_mom = true;
+                        if (NW == 1) {
+                            // one-wave forms: the pass runs at the loop's evaluation site (like an evaluation, nothing of this block
+                            // is live across it); its operands go through the LDS.  (Two-wave form: done with the first evaluation.)
+                            mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);   // (before sv is an operand)
+#pragma unroll
+                            for (int r = 0; r < VPL; ++r) {
+                                const int i = lane + WAVE * r;
+                                const double el = (i < n) ? e[r] : (i == n ? eK : 0.0), pl = (i < n) ? p[r] : 0.0;
+                                se[i] = el; sv[i] = el * pl; sw[i] = (el * pl) * pl;
+                            }
+                            STM_WAVE_SYNC();
+                        }
                     }
                 }
                 phi0 = old_fval;
                 old_phi0 = old_old_fval;
                 st = S_W1_START;
-                if (MOM && want_mom) { st = S_MOMENTS; break; }
+                if (MOM && want_mom) {
+                    st = S_MOMENTS;
+                    if (NW == 1) break;      // through the loop top for the pass
+                    want_mom = false;        // two-wave form: straight to the verdict
+                }
             } [[fallthrough]];
             case S_MOMENTS:
             case S_W1_START: {  // scalar_search_wolfe1 + DCSRCH START
