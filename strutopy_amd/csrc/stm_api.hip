@@ -121,6 +121,7 @@ struct stm_handle {
     std::vector<int32_t> h_len_sorted;   // document lengths in processing order (longest first)
     int64_t *d_indptr = nullptr;
     int32_t *d_indices = nullptr, *d_aspect = nullptr, *d_order = nullptr;
+    int64_t *d_tick = nullptr;           // per ticket of the longest-first order: {indptr[doc], doc | Nd << 32} (one scalar load instead of two dependent ones)
     double *d_counts = nullptr;
     // the corpus in word-major order (stm_betass.h): entries sorted by (level, word), ascending document within a row
     int32_t *d_wm_doc = nullptr, *d_wm_pos = nullptr, *d_cptr = nullptr;
@@ -427,7 +428,7 @@ void stm_destroy(stm_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     stm_mstep_comm_destroy(h->comm);
     stm_spectral_destroy(h->spectral);
-    dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_counts);
+    dfree(h->d_indptr); dfree(h->d_indices); dfree(h->d_aspect); dfree(h->d_order); dfree(h->d_tick); dfree(h->d_counts);
     dfree(h->d_wm_doc); dfree(h->d_wm_pos); dfree(h->d_rw); dfree(h->d_cptr); dfree(h->d_bss_part);
     dfree(h->d_red); dfree(h->d_betaT); dfree(h->d_tmpKV); dfree(h->d_colsum); dfree(h->d_eta); dfree(h->d_mu);
     dfree(h->d_theta); dfree(h->d_bound); dfree(h->d_siginv); dfree(h->d_sigma_part);
@@ -484,6 +485,7 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     if (int rc = dalloc(&h->d_indices, (size_t)nnz)) return rc;
     if (int rc = dalloc(&h->d_counts, (size_t)nnz)) return rc;
     if (int rc = dalloc(&h->d_order, (size_t)N)) return rc;
+    if (int rc = dalloc(&h->d_tick, 2 * (size_t)N)) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_indptr, indptr, sizeof(int64_t) * (size_t)(N + 1), hipMemcpyHostToDevice, h->stream));
     if (nnz) {
         HIP_TRY(hipMemcpyAsync(h->d_indices, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
@@ -501,6 +503,16 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
         return (indptr[a + 1] - indptr[a]) > (indptr[b + 1] - indptr[b]);
     });
     if (N) HIP_TRY(hipMemcpyAsync(h->d_order, order.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    {
+        std::vector<int64_t> tick(2 * (size_t)N);
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t d = order[(size_t)i];
+            tick[2 * (size_t)i] = indptr[d];
+            tick[2 * (size_t)i + 1] = d | ((indptr[d + 1] - indptr[d]) << 32);
+        }
+        if (N) HIP_TRY(hipMemcpyAsync(h->d_tick, tick.data(), sizeof(int64_t) * 2 * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));   // (tick is a local)
+    }
     h->h_len_sorted.resize((size_t)N);
     for (int64_t i = 0; i < N; ++i) h->h_len_sorted[(size_t)i] = (int32_t)(indptr[order[i] + 1] - indptr[order[i]]);
     // word-major order (stm_betass.h): a counting sort of the CSR positions by (level, word, document chunk); documents
@@ -771,7 +783,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     sp.indptr = h->d_indptr; sp.indices = h->d_indices; sp.counts = h->d_counts; sp.aspect = h->d_aspect;
     sp.betaT = h->d_betaT; sp.colsum = h->d_colsum; sp.mu = h->d_mu; sp.eta = h->d_eta; sp.siginv = h->d_siginv; sp.siginv_diag = diag; sp.sig_bound = sig_bound;
     sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
-    sp.order = h->d_order; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
+    sp.order = h->d_order; sp.tick = h->d_tick; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
     sp.err_flag = h->d_err;
     sp.debug_flags = env_int("STM_DEBUG_FLAGS", 0);
     sp.prof = h->d_prof;
@@ -781,7 +793,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     pp.indptr = h->d_indptr; pp.indices = h->d_indices; pp.counts = h->d_counts; pp.aspect = h->d_aspect;
     pp.betaT = h->d_betaT; pp.mu = h->d_mu; pp.eta = h->d_eta; pp.siginv = h->d_siginv; pp.siginv_diag = diag;
     pp.sigmaentropy = sigmaentropy; pp.theta = h->d_theta; pp.bound = h->d_bound; pp.beta_ssT = h->d_beta_ssT;
-    pp.sigma_part = h->d_sigma_part; pp.nrep = h->nrep; pp.order = h->d_order;
+    pp.sigma_part = h->d_sigma_part; pp.nrep = h->nrep; pp.order = h->d_order; pp.tick = h->d_tick;
     pp.pd_path = h->d_pd; pp.err_flag = h->d_err;
     pp.hess_out = h->d_hess; pp.chol_out = h->d_chol; pp.nu_out = h->d_nu;
     pp.phi_doc = h->phi_doc; pp.phi_out = h->d_phi;

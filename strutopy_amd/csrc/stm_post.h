@@ -126,9 +126,16 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         }
         const int64_t ticket = P.first + tk;
         // the document header through the scalar cache (uniform, constant for the kernel's lifetime)
-        const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
-        const int64_t p0 = scalar_load(P.indptr + doc);
-        const int Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
+        int64_t doc, p0;
+        int Nd;
+        if (P.tick) {
+            const int64_t t0 = scalar_load(P.tick + 2 * ticket), t1 = scalar_load(P.tick + 2 * ticket + 1);
+            p0 = t0; doc = t1 & 0xffffffffLL; Nd = (int)(t1 >> 32);
+        } else {
+            doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
+            p0 = scalar_load(P.indptr + doc);
+            Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
+        }
         const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
         long long tp[8];

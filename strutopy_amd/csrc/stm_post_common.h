@@ -28,6 +28,7 @@ struct PostParams {
     int64_t first;         // this launch covers order[first .. first + count)
     int64_t count;
     const int32_t *order;
+    const int64_t *tick;   // optional [N][2]: ticket -> {indptr[doc], doc | Nd << 32} (the header in one scalar load; nullable)
     int32_t *pd_path;
     int32_t *err_flag;
     double *hess_out, *chol_out, *nu_out;  // optional [N][n][n] dumps (nullable)

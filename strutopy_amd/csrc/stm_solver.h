@@ -62,6 +62,7 @@ struct SolverParams {
     int KP;                 // slab row length: K rounded up to 4j+2 (16-byte rows, conflict-free ds_read_b128)
     int64_t first;          // this launch covers order[first .. first + gridDim.x)
     const int32_t *order;   // optional processing order (nullable)
+    const int64_t *tick;    // optional [N][2]: ticket -> {indptr[doc], doc | Nd << 32} of that order (nullable: the header is read through order / indptr)
     int32_t *status, *nit, *nfev, *njev;
     int32_t *err_flag;
     int lds_doubles;        // dynamic LDS of this launch, in doubles (debug bit3 poisons it)
@@ -273,9 +274,17 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             __syncthreads();
         }
         const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
-        const int64_t doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
-        const int64_t p0 = scalar_load(P.indptr + doc);
-        const int Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
+        // the document's header: one 16-byte scalar load (order -> indptr would be two dependent round trips before the first index load)
+        int64_t doc, p0;
+        int Nd;
+        if (P.tick) {
+            const int64_t t0 = scalar_load(P.tick + 2 * ticket), t1 = scalar_load(P.tick + 2 * ticket + 1);
+            p0 = t0; doc = t1 & 0xffffffffLL; Nd = (int)(t1 >> 32);
+        } else {
+            doc = P.order ? (int64_t)scalar_load(P.order + ticket) : ticket;
+            p0 = scalar_load(P.indptr + doc);
+            Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
+        }
         const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
         const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
@@ -1137,8 +1146,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         words_F3(uni(xch_res[2]), NdL, part, d1, d2);
                         part = wave_sum(part); d1 = wave_sum(d1); d2 = wave_sum(d2);
                         const double g0p = wave_sum(g0[0] * pl);
-                        const double qd = quad_of([&](int) __attribute__((always_inline)) -> double { return pl; }, svx);
-                        if (lane == 0) { xch_res[0] = part; xch_res[1] = q; xch_res[3] = g0p; xch_res[4] = qd; xch_res[5] = d1; xch_res[6] = d2; }
+                        if (lane == 0) { xch_res[0] = part; xch_res[1] = q; xch_res[3] = g0p; xch_res[5] = d1; xch_res[6] = d2; }
                         __syncthreads();  // (2) results posted
                         continue;
                     }
@@ -1225,11 +1233,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             double part, d1, d2;
             words_F3(m, 0, part, d1, d2);   // words 0..63 (wave 1 owns the slab)
             part = wave_sum(part); d1 = wave_sum(d1); d2 = wave_sum(d2);
+            // p^T siginv p here: wave 1 is still on the slab words (its private vector svb is free from barrier (1) on)
+            qx_out = quad_of([&](int r) __attribute__((always_inline)) -> double { return -gv[r]; }, svb);
             __syncthreads();   // (2)
             const double part_all = part + uni(xch_res[0]);
             const double q = uni(xch_res[1]);
             f_out = 0.5 * q - (part_all - Ndoc * lse);
-            D1_out = d1 + uni(xch_res[5]); D2_out = py_max2(0.0, d2 + uni(xch_res[6])); g0p_out = uni(xch_res[3]); qx_out = uni(xch_res[4]);
+            D1_out = d1 + uni(xch_res[5]); D2_out = py_max2(0.0, d2 + uni(xch_res[6])); g0p_out = uni(xch_res[3]);
         };
 
         auto dot = [&](const double (&a)[VPL], const double (&b)[VPL]) __attribute__((always_inline)) -> double {
