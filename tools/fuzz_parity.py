@@ -3,7 +3,10 @@
 cases of tests/test_gpu_parity.py).  Random K, V, document lengths, counts, eta / mu scales, diagonal or dense siginv, one or
 several beta levels; scipy status / nit / PD path must agree exactly, values to the tolerances of DESIGN.md section 7.
 
-    python tools/fuzz_parity.py [n_cases] [seed] [long]      # long: vocabularies up to 9000 and one document using most of it
+    python tools/fuzz_parity.py [n_cases] [seed] [long|warm]  # long: vocabularies up to 9000 and one document using most of it
+                                                              # warm: a SECOND E-step per case, started at the first one's eta with beta and
+                                                              # mu perturbed like an M-step would -- the regime of EM iterations >= 1, where the
+                                                              # first line search mostly cannot succeed and the solver's moment pass decides
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +18,9 @@ from strutopy_amd.engine import estep_host
 stm_oracle.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
-LONG = len(sys.argv) > 3
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
+WARM = len(sys.argv) > 3 and sys.argv[3] == "warm"
+fired = [0, 0]
 bad = 0
 for case in range(n_cases):
     K = int(rng.choice([2, 3, 5, 10, 16, 17, 18, 33, 34, 49, 50, 51, 64, 65, 80, 100, 128]))
@@ -47,6 +52,13 @@ for case in range(n_cases):
     else:
         Bm = rng.normal(size=(n, n)); sigma = Bm @ Bm.T + np.eye(n) * n
         siginv, sigent = np.linalg.inv(sigma), float(0.5 * np.linalg.slogdet(sigma)[1])   # a dense siginv
+    if WARM:   # the second E-step of an EM run: warm start, parameters moved a little
+        o1 = stm_oracle.estep(indptr, indices, counts, beta, mu, eta, siginv, sigent, aspect=aspect, nthreads=0)
+        eta = o1["eta"]
+        step = float(rng.choice([0.01, 0.05, 0.2]))
+        beta = beta * np.exp(step * rng.standard_normal(beta.shape))
+        beta /= beta.sum(axis=-1, keepdims=True)
+        mu = mu + step * rng.standard_normal(mu.shape)
     args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
     tag = f"case {case}: K={K} V={V} N={N} maxlen={maxlen} A={A} scale={scale} dense={not np.allclose(siginv, np.diag(np.diag(siginv)))}"
     try:
@@ -55,6 +67,9 @@ for case in range(n_cases):
     except Exception as e:   # both sides should raise alike; report and go on
         print(tag, "EXCEPTION", repr(e)); bad += 1; continue
     msgs = []
+    if WARM:   # how often the moment pass decided: documents that stay put with one evaluation on the device
+        still = o["nit"] == 0
+        fired[0] += int(np.sum(still & (d["nfev"] <= 2))); fired[1] += int(np.sum(still))
     for k in ("status", "nit", "pd_path"):
         if not np.array_equal(d[k], o[k]):
             msgs.append(f"{k} differs in {int(np.sum(d[k] != o[k]))} documents")
@@ -84,5 +99,7 @@ for case in range(n_cases):
                             mu=mu, eta=eta, siginv=siginv, sigent=sigent, aspect=aspect if aspect is not None else np.zeros(0, np.int32),
                             d_pd=d["pd_path"], o_pd=o["pd_path"], d_bound=d["bound_doc"], o_bound=o["bound_doc"], d_sigma_ss=d["sigma_ss"],
                             o_sigma_ss=o["sigma_ss"], d_eta=d["eta"], o_eta=o["eta"])
+if WARM:
+    print(f"warm starts: {fired[1]} documents did not move, {fired[0]} of them finished within two evaluations (moment pass)")
 print(f"{n_cases - bad} of {n_cases} cases agree")
 sys.exit(1 if bad else 0)
