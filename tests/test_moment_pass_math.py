@@ -1,0 +1,119 @@
+"""The solver's moment pass (strutopy_amd/csrc/stm_solver.h, S_MOMENTS) restated in NumPy and checked against the
+reference's own outcomes -- no GPU.
+
+The pass is NOT part of the reference: it is a sufficient condition under which scipy's first line search
+(p = -df(x0), stm.py:917-962 through scipy.optimize.minimize(method="BFGS")) cannot succeed, so that the HIP solver may
+return status 2 / nit 0 / eta unchanged without executing the ~60 evaluations scipy spends finding that out.  A
+sufficient condition that is ever true for a document the reference MOVES would break parity; this test evaluates the
+verdict, exactly as the kernel does, on every document of tests/golden/k50_late.npz (the reference's EM iterations
+3, 4, 5, 8 at K=50 with their complete input state, 4 x 2000 documents) and requires
+
+  * soundness: verdict "dead"  ==>  the reference ended with nit == 0 and status == 2 (eta_out == eta_in), and
+  * usefulness: from EM iteration 4 on it decides at least 85 % of the documents that do not move.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+C1 = 1e-4
+
+
+def _verdict(x, mu, siginv, bd, c):
+    """One document.  x: eta (K-1), bd: beta_d (K x Nd), c: counts.  Returns True when the first search is proven dead."""
+    K = bd.shape[0]
+    n = K - 1
+    N = float(int(c.sum()))
+    xt = np.append(x, 0.0)
+    m = xt.max()
+    e = np.exp(xt - m)
+    theta = e / e.sum()
+    g0 = bd @ (c / bd.sum(axis=0))                                    # df's constant data term (stm.py:954)
+    g = siginv @ (x - mu) - (g0 - (N / np.exp(xt).sum()) * np.exp(xt))[:-1]
+    if not np.abs(g).max() > 1e-5:
+        return False
+    p = -g
+    derphi0 = float(g @ p)
+    pt = np.append(p, 0.0)
+    rng_ = pt.max() - pt.min()
+    if not (derphi0 < 0.0 and rng_ > 0.0):
+        return False
+    # Lipschitz bounds of phi'' (S_OUTER_TOP)
+    sig_lmax = np.abs(siginv).sum(axis=1).max()
+    diag = np.count_nonzero(siginv - np.diag(np.diag(siginv))) == 0
+    pp = float(p @ p)
+    Lb = sig_lmax * pp + N * 0.25 * rng_ * rng_
+    cm = float(theta @ pt)
+    var0 = float(theta @ (pt - cm) ** 2)
+    qx = float(p @ siginv @ p)
+    Lv = ((qx if diag else sig_lmax * pp) + N * var0) * (1.0 + 1e-9)
+    # moments of p~ under q_w(k) ~ beta_d[k, w] exp(eta~_k)
+    S0, S1, S2 = e @ bd, (e * pt) @ bd, (e * pt * pt) @ bd
+    m1 = S1 / S0
+    D1 = float(c @ m1)
+    D2 = max(0.0, float(c @ (S2 / S0 - m1 * m1)))
+    g0p = float(g0[:-1] @ p)
+    # first trial step of DCSRCH and wolfe2 at k = 0: old_old_fval = f0 + |g| / 2
+    b = min(1.0, 1.01 * 2 * (-(np.linalg.norm(g) / 2)) / derphi0)
+    if b < 0:
+        b = 1.0
+    slope0 = -derphi0
+    nv = N * var0
+    a0 = ((derphi0 + g0p) - D1) + C1 * slope0
+    a0tol = 1e-9 * (slope0 + abs(g0p) + abs(D1))
+    if not (np.isfinite(b) and b > 0.0 and qx >= 0.0 and a0 + b * (qx + nv) > 0.0):
+        return False
+    s0 = 0.09 * slope0 / Lv
+    t0 = s0 * rng_
+    Ux = min(Lb, Lv * (1.0 + t0 + t0 * t0)) if t0 <= 1.0 else Lb
+    sx = min(0.09 * slope0 / Ux, b)
+    ir = 1.0 / rng_
+
+    def hH(sq):
+        t = sq * rng_
+        et = np.exp(t)
+        eti = 1.0 / et
+        small = t < 0.05
+        A = t - 0.5 * t * t if small else 1.0 - eti
+        B = t + 0.5 * t * t * et if small else et - 1.0
+        C = t * t * (0.5 - t / 6.0) if small else (t - 1.0) + eti
+        E = t * t * (0.5 + t / 6.0 * et) if small else (et - 1.0) - t
+        up1, dn1 = nv * (A * ir), D2 * (B * ir)
+        up2, dn2 = nv * ((C * ir) * ir), D2 * ((E * ir) * ir)
+        h = (a0 + qx * sq + up1 - dn1) - (a0tol + 1e-9 * (qx * sq + up1 + dn1))
+        H = (a0 * sq + 0.5 * qx * sq * sq + up2 - dn2) - (a0tol * sq + 1e-9 * (0.5 * qx * sq * sq + up2 + dn2))
+        return h, H
+
+    # f(x0) only enters through the rounding allowance of f
+    f0 = 0.5 * (x - mu) @ siginv @ (x - mu) - (c @ (m + np.log(e @ bd)) - N * (m + np.log(e.sum())))
+    fm = 1e-9 * max(1.0, abs(f0))
+    _, Hb = hH(b)
+    if not (Ux > 0.0 and sx > 0.0 and Hb >= fm):
+        return False
+    if sx >= b:
+        return True
+    hx, Hx = hH(sx)
+    return bool(hx > 0.0 and Hx >= fm)
+
+
+@pytest.mark.parametrize("it", [3, 4, 5, 8])
+def test_moment_verdict_is_sound_on_the_reference_runs(it):
+    g = load_golden("k50_late")
+    p = f"it{it}_"
+    beta, eta_in, mu, siginv = g[p + "beta_in"], g[p + "eta_in"], g[p + "mu_in"], g[p + "siginv"]
+    indptr, indices, counts = g["indptr"], g["indices"], g["counts"]
+    nit, status, eta_out = g[p + "nit"], g[p + "status"], g[p + "eta"]
+    N = len(indptr) - 1
+    dead = np.zeros(N, dtype=bool)
+    for d in range(N):
+        w = indices[indptr[d]:indptr[d + 1]]
+        dead[d] = _verdict(eta_in[d], mu[d], siginv, beta[:, w], counts[indptr[d]:indptr[d + 1]])
+    # soundness: every document the verdict stops is one the reference left where it was
+    assert np.all(nit[dead] == 0), f"verdict 'dead' for {int(np.sum(nit[dead] != 0))} documents the reference moves"
+    assert np.all(status[dead] == 2)
+    assert np.array_equal(eta_out[dead], eta_in[dead])
+    # usefulness
+    still = nit == 0
+    if it >= 4:
+        assert still.mean() > 0.3
+        assert dead.sum() >= 0.85 * still.sum(), f"it{it}: {int(dead.sum())} of {int(still.sum())} still documents decided"
