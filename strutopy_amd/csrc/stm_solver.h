@@ -1630,7 +1630,13 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     const double smax = py_max2(stx, sty), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
                     if (smax * Ls <= 0.05 * -derphi0) { st = S_W2_START; break; }
-                    if (stx == 0.0 && sty > 0.0 && armijo_dead(sty, fy)) { st = S_W2_START; break; }
+                    if (stx == 0.0 && sty > 0.0 && armijo_dead(sty, fy)) {
+                        // Rejected at DCSRCH's FIRST step: wolfe2 starts at the same step (the same expression of phi0, old_phi0,
+                        // derphi0), reuses f there (S_W2_START), finds it above the sufficient-decrease line (armijo_dead implies
+                        // that) and calls _zoom(0, alpha1), where S_ZOOM_TOP applies this very test to the same numbers -> status 2.
+                        if (reuse && w1_have && w1_calls == 2) { ++nfev; status = 2; st = S_FINISH; break; }
+                        st = S_W2_START; break;
+                    }
                 }
                 alpha = stp; need_f = true; need_g = true; want_eval = true;
                 st = S_W1_ITER;
