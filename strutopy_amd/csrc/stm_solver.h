@@ -1297,6 +1297,11 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
 
         // ---- scipy _minimize_bfgs state (optimize/_optimize.py:1328-1502)
         const double gtol = 1e-5, c1 = 1e-4, c2 = 0.9, amax = 1e100, amin = 1e-100, xtol = 1e-14;
+        // The curvature test |phi'(s)| <= c2 |phi'(0)| is out of reach on [0, s] while s U <= CURV |phi'(0)| (U >= phi''): then
+        // |phi'(s)| >= 0.91 |phi'(0)|, against the 0.9 |phi'(0)| the test needs -- a margin of 1 % of |phi'(0)|, where the rounding of
+        // phi' = df . p is ~1e-13 of it.  (Rounds 1-3 used 0.05: late EM iterations showed searches whose bracket closes on a
+        // minimiser of f at 0.5-0.9 of the reach and never gets below half of it -- ~50 evaluations each until DCSRCH gives up.)
+        const double CURV = 0.09;
         const int maxiter = n * 200;
         STM_UD(ss, old_fval); STM_UD(ss, old_old_fval); STM_UD(ss, gnorm);
         int k = 0, status = 0;
@@ -1330,18 +1335,18 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // (U as in S_OUTER_TOP; the data term only lowers it).  With f(0) and a rejected f(b) known, the chord
         // bound f(s) >= f(0) + s (f(b) - f(0)) / b - U s (b - s) / 2 shows that the sufficient-decrease test
         // f(s) <= f(0) + c1 s phi'(0), which DCSRCH and _zoom both require of an accepted step, fails on all of
-        // (0, b) when (f(b) - f(0)) / b + c1 |phi'(0)| > U b / 2.  Below s_lo = 0.05 |phi'(0)| / U the curvature test
+        // (0, b) when (f(b) - f(0)) / b + c1 |phi'(0)| > U b / 2.  Below s_lo = CURV |phi'(0)| / U the curvature test
         // is out of reach (first cut); above it the violation s * margin must dwarf the rounding of f.
         auto armijo_dead = [&](double b, double phi_b) __attribute__((always_inline)) -> bool {
             const double tr = b * prange;
             const double U = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
             const double slope0 = -derphi0;
-            // margin = (phi_b - phi0) / b + c1 slope0 - U b / 2 and s_lo = 0.05 slope0 / U, both multiplied through by b > 0 and U > 0:
+            // margin = (phi_b - phi0) / b + c1 slope0 - U b / 2 and s_lo = CURV slope0 / U, both multiplied through by b > 0 and U > 0:
             // two IEEE divisions less on the state machine's dependency chain (the inequalities are sufficient conditions with a
             // 1e-9 margin, so their last-bit rounding is immaterial)
             const double margin_b = (phi_b - phi0) + b * (c1 * slope0 - 0.5 * U * b);
             return slope0 > 0.0 && b > 0.0 && U > 0.0 && margin_b > 0.0 &&
-                   0.05 * slope0 * margin_b >= 1e-9 * py_max2(1.0, fabs((double)phi0)) * (U * b);
+                   CURV * slope0 * margin_b >= 1e-9 * py_max2(1.0, fabs((double)phi0)) * (U * b);
         };
 
         if (P.debug_flags & 1) st = S_FINISH;
@@ -1515,9 +1520,9 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     bool dead = false;
                     // h <= a0 + s (p^T siginv p + N_d var0): two out of five documents leave here (f falls along p)
                     if (finite_d(b) && b > 0.0 && qx >= 0.0 && a0 + b * (qx + nv) > 0.0) {
-                        const double s0 = 0.09 * slope0 / Lv, t0 = s0 * range;
+                        const double s0 = CURV * slope0 / Lv, t0 = s0 * range;
                         const double Ux = (t0 <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + t0 + t0 * t0)) : (double)Lb;
-                        const double sx = py_min2(0.09 * slope0 / Ux, b);
+                        const double sx = py_min2(CURV * slope0 / Ux, b);
                         const double ir = 1.0 / range, fm = 1e-9 * py_max2(1.0, fabs((double)phi0));
                         // lower bounds of h(s) and H(s) (reciprocals instead of quotients: inside the 1e-9 allowance)
                         auto hH = [&](double sq, double &h_out, double &H_out) __attribute__((always_inline)) {
@@ -1622,14 +1627,14 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 // whose quadratic form in p is p^T siginv p plus N_d times the variance of [p, 0] under theta,
                 // at most a quarter of its squared range whatever theta is (Lb is set in S_OUTER_TOP).
                 // DCSRCH reports convergence only if |phi'(s)| <= 0.9 |phi'(0)|, impossible while
-                // smax Lb < 0.1 |phi'(0)| (tested with a 2x margin for the rounding of phi').  What
+                // smax Lb < 0.1 |phi'(0)| (tested as smax Ls <= CURV |phi'(0)|, see CURV).  What
                 // remains is ~60 evaluations inside rounding noise that can only end in a WARNING or
                 // the 100-call cap, i.e. alpha = None and the hand-over to wolfe2, whose start does
                 // not depend on DCSRCH's final state.
                 if (brackt && cuts) {
                     const double smax = py_max2(stx, sty), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
-                    if (smax * Ls <= 0.05 * -derphi0) { st = S_W2_START; break; }
+                    if (smax * Ls <= CURV * -derphi0) { st = S_W2_START; break; }
                     if (stx == 0.0 && sty > 0.0 && armijo_dead(sty, fy)) {
                         // Rejected at DCSRCH's FIRST step: wolfe2 starts at the same step (the same expression of phi0, old_phi0,
                         // derphi0), reuses f there (S_W2_START), finds it above the sufficient-decrease line (armijo_dead implies
@@ -1706,7 +1711,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 if (cuts && a_lo >= 0 && a_hi >= 0) {
                     const double smax = py_max2(a_lo, a_hi), tr = smax * prange;
                     const double Ls = (tr <= 1.0) ? py_min2((double)Lb, Lv * (1.0 + tr + tr * tr)) : (double)Lb;
-                    if (smax * Ls <= 0.05 * -derphi0) { status = 2; st = S_FINISH; break; }
+                    if (smax * Ls <= CURV * -derphi0) { status = 2; st = S_FINISH; break; }
                     if (a_lo == 0.0 && a_hi > 0.0 && armijo_dead(a_hi, phi_hi)) { status = 2; st = S_FINISH; break; }
                 }
                 const double dalpha = a_hi - a_lo;
