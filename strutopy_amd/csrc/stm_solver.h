@@ -1298,10 +1298,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // ---- scipy _minimize_bfgs state (optimize/_optimize.py:1328-1502)
         const double gtol = 1e-5, c1 = 1e-4, c2 = 0.9, amax = 1e100, amin = 1e-100, xtol = 1e-14;
         // The curvature test |phi'(s)| <= c2 |phi'(0)| is out of reach on [0, s] while s U <= CURV |phi'(0)| (U >= phi''): then
-        // |phi'(s)| >= 0.91 |phi'(0)|, against the 0.9 |phi'(0)| the test needs -- a margin of 1 % of |phi'(0)|, where the rounding of
+        // |phi'(s)| >= 0.901 |phi'(0)|, against the 0.9 |phi'(0)| the test needs -- a margin of 0.1 % of |phi'(0)|, where the rounding of
         // phi' = df . p is ~1e-13 of it.  (Rounds 1-3 used 0.05: late EM iterations showed searches whose bracket closes on a
         // minimiser of f at 0.5-0.9 of the reach and never gets below half of it -- ~50 evaluations each until DCSRCH gives up.)
-        const double CURV = 0.09;
+        const double CURV = 0.099;
         const int maxiter = n * 200;
         STM_UD(ss, old_fval); STM_UD(ss, old_old_fval); STM_UD(ss, gnorm);
         int k = 0, status = 0;

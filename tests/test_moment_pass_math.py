@@ -17,6 +17,7 @@ import pytest
 from conftest import load_golden
 
 C1 = 1e-4
+CURV = 0.099   # the kernel's margin on the curvature test's reach (stm_solver.h)
 
 
 def _verdict(x, mu, siginv, bd, c):
@@ -63,10 +64,10 @@ def _verdict(x, mu, siginv, bd, c):
     a0tol = 1e-9 * (slope0 + abs(g0p) + abs(D1))
     if not (np.isfinite(b) and b > 0.0 and qx >= 0.0 and a0 + b * (qx + nv) > 0.0):
         return False
-    s0 = 0.09 * slope0 / Lv
+    s0 = CURV * slope0 / Lv
     t0 = s0 * rng_
     Ux = min(Lb, Lv * (1.0 + t0 + t0 * t0)) if t0 <= 1.0 else Lb
-    sx = min(0.09 * slope0 / Ux, b)
+    sx = min(CURV * slope0 / Ux, b)
     ir = 1.0 / rng_
 
     def hH(sq):
