@@ -11,8 +11,14 @@ ND, VV, KK = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (20000, 1
 ITS = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 FIRST = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 syn = synthetic_corpus(ND, VV, KK, n_words=150, seed=12345)
-m = STM(documents=syn.corpus, dictionary=None, content=False, K=KK, X=syn.X, kappa_interactions=False, max_em_iter=ITS,
-        sigma_prior=0, convergence_threshold=1e-9, init_type="random")
+LEVELS = int(os.environ.get("PROF_LEVELS", "1"))   # 2: config 5's content covariate (document level ~ uniform, as bench.py)
+if LEVELS > 1:
+    aspect = np.random.default_rng(777).integers(0, LEVELS, size=ND).astype(np.int32)
+    m = STM(documents=syn.corpus, dictionary=None, content=True, K=KK, X=syn.X, kappa_interactions=True, A=LEVELS, beta_index=aspect,
+            max_em_iter=ITS, sigma_prior=0, convergence_threshold=1e-9, init_type="random")
+else:
+    m = STM(documents=syn.corpus, dictionary=None, content=False, K=KK, X=syn.X, kappa_interactions=False, max_em_iter=ITS,
+            sigma_prior=0, convergence_threshold=1e-9, init_type="random")
 for it in range(ITS):
     m._em_iteration_resident()
     out = np.zeros((m.N, 48), dtype=np.int64)
