@@ -1474,8 +1474,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     //   f'(s) - c1 phi'(0) >= a0 + s p^T siginv p + N_d var0 (1 - e^{-s r}) / r - D2 (e^{s r} - 1) / r =: h(s),
                     //   a0 = f'(0) + c1 |phi'(0)| with the TRUE slope f'(0) = phi'(0) + g0 . p - D1, D1 = D'(0) (df's data term is the constant g0),
                     // so f(s) - [f(0) + c1 s phi'(0)] >= H(s) = int_0^s h.  h is concave (h'' <= 0).
-                    // (1) For s < s_x = 0.09 |phi'(0)| / U' (U' >= phi'' on [0, s_x], Lb / Lv as above) the curvature test
-                    //     |phi'(s)| <= 0.9 |phi'(0)| is out of reach: |phi'(s)| >= 0.91 |phi'(0)| (the dot product's rounding is 1e-13 of it).
+                    // (1) For s < s_x = CURV |phi'(0)| / U' (U' >= phi'' on [0, s_x], Lb / Lv as above) the curvature test
+                    //     |phi'(s)| <= 0.9 |phi'(0)| is out of reach: |phi'(s)| >= 0.901 |phi'(0)| (the dot product's rounding is 1e-13 of it).
                     // (2) If h(s_x) > 0, H rises and then at most falls on [s_x, b], so H >= min(H(s_x), H(b)) there; when that exceeds the
                     //     rounding of f (1e-9 max(1, |f|), as in armijo_dead) the sufficient-decrease test fails on all of [s_x, b].
                     // b = the first trial step of DCSRCH and of wolfe2 (the same number): it is rejected by (2), which brackets [0, b], and
