@@ -617,6 +617,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // quarters combined by two exchanges -- every lane of a word ends up with the word's total
         const int dw = lane & 15, dq = lane >> 4;
         const int kq2 = ((KP >> 1) + 3) >> 2;                       // 16-byte pieces per quarter
+        // DIRECT: ONE sweep over the document's rows for g0, f(x0)'s data term and the moment test's vector (after eval_DF below)
+        const bool fuse0 = DIRECT && !(P.debug_flags & (1 | 2 | 16));
         if constexpr (DIRECT) {
             if (NdL > 0) STM_WAVE_SYNC();                            // sidx / crow visible to the wave
             // c / colsum(beta_d) for every word up front (the column sum is a property of the word, P.colsum): inside the tile
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             double g0a[VPL];
 #pragma unroll
             for (int r = 0; r < VPL; ++r) g0a[r] = 0.0;
-            tile_fetch(0);
-            for (int t0 = 0; t0 < NdL; t0 += TWS) {
+            if (!fuse0) tile_fetch(0);   // (fuse0: g0 comes out of the one sweep that also serves f(x0) and the moment test, below)
+            for (int t0 = 0; !fuse0 && t0 < NdL; t0 += TWS) {
                 const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
                 tile_store();
                 STM_WAVE_SYNC();
@@ -998,35 +1000,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     d1 = in ? cw * m1 : 0.0;
                     d2 = in ? cw * var : 0.0;
                 }
-                if constexpr (DIRECT) {   // tile by tile, lane = (word, quarter of the topics), as data_F
-                    tile_fetch(0);
-                    const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
-                    for (int t0 = 0; t0 < NdL; t0 += TWS) {
-                        const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
-                        tile_store();
-                        STM_WAVE_SYNC();
-                        if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
-                        const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);
-                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
-#pragma unroll 2
-                        for (int kk = k0; kk < k1; ++kk) {
-                            const double2 e = se2[kk], u = sv2[kk], v = sw2[kk], bb = tr[kk];
-                            a0 = fma(e.x, bb.x, a0); a1 = fma(e.y, bb.y, a1);
-                            b0 = fma(u.x, bb.x, b0); b1 = fma(u.y, bb.y, b1);
-                            q0 = fma(v.x, bb.x, q0); q1 = fma(v.y, bb.y, q1);
-                        }
-                        double s0 = a0 + a1, s1 = b0 + b1, s2 = q0 + q1;
-                        s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                        s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                        double m1, var;
-                        mv(s0, s1, s2, m1, var);
-                        const bool in = dq == 0 && dw < nw;
-                        const double cw = crow[t0 + (dw < nw ? dw : 0)];
-                        d1 += in ? cw * m1 : 0.0;
-                        d2 += in ? cw * var : 0.0;
-                        STM_WAVE_SYNC();
-                    }
-                } else {
+                if constexpr (!DIRECT) {   // (DIRECT: the fused set-up sweep below delivers the sums)
                     const int kp2 = KP >> 1;
                     for (int vb = 0; vb < NdL; vb += WAVE) {
                         const int va = vb + lane, ia = va < NdL ? va : NdL - 1;
@@ -1091,6 +1065,100 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 }
                 STM_WAVE_SYNC();
             }
+        };
+
+        // ---- DIRECT (K > 64), fused set-up sweep.  Every pass over the document re-gathers its rows (~80 k cycles at K = 100), and a
+        // document whose first search is dead needed three of them: g0, f(x0), the moments.  All three come out of one:
+        //   (1) g0 += beta_d[:, tile] (c / colsum)                       lane = topic           (as the set-up sweep it replaces)
+        //   (2) S_w = sum_k beta_d[k, w] exp(eta~_k - m), c_w log S_w     lane = (word, quarter) (data_F's sums, chain for chain)
+        //   (3) v += beta_d[:, tile] (c / S)                              lane = topic
+        // v_k exp(eta~_k - m) = dD/d eta~_k, the data term of the TRUE gradient of f at x0.  The moment test (S_OUTER_TOP) needs
+        // D1 = D'(0) = v . p~ -- exact -- and an upper bound of D2 = sum_w c_w Var_{q_w}(p~): a variance is at most the mean square
+        // about ANY constant a, so D2 <= sum_w c_w E_{q_w}[(p~ - a)^2] = sum_k v_k (p~_k - a)^2 (a = D1 / N_d).  That is 1.3-2x the
+        // exact D2 on traced data and proves 92-97 % of what the exact one proves -- without the second sweep p would have to wait for.
+        double part0 = 0.0, vdat[VPL];
+        bool have0 = false;
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) vdat[r] = 0.0;
+        if constexpr (DIRECT) {
+            if (fuse0) {
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) xt[r] = x[r];
+                double m0, ssum0, e_l = 0.0;
+                int icnt0;
+                head_F(m0, icnt0, ssum0, e_l);     // exp(eta~ - m) -> se[] (the first evaluation recomputes it: no sweep)
+                STM_WAVE_SYNC();
+                double g0a[VPL], va[VPL], part = 0.0;
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) { g0a[r] = 0.0; va[r] = 0.0; }
+                const double2 *se2 = reinterpret_cast<const double2 *>(se);
+                const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
+                tile_fetch(0);
+                for (int t0 = 0; t0 < NdL; t0 += TWS) {
+                    const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
+                    tile_store();
+                    STM_WAVE_SYNC();
+                    if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
+#pragma unroll 4
+                    for (int w = 0; w < nw; ++w) {   // (1)
+                        const double wq = wrow[t0 + w];
+#pragma unroll
+                        for (int r = 0; r < VPL; ++r)
+                            if (lane + WAVE * r < KP) {
+                                const double bv = slab[(size_t)w * KP + lane + WAVE * r];
+                                g0a[r] = fma(bv, wq, g0a[r]);
+                            }
+                    }
+                    const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);   // (2)
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 4
+                    for (int kk = k0; kk < k1; ++kk) {
+                        const double2 e = se2[kk], b = tr[kk];
+                        a0 = fma(e.x, b.x, a0);
+                        a1 = fma(e.y, b.y, a1);
+                    }
+                    double sdot = a0 + a1;
+                    sdot += __shfl_xor(sdot, 16);
+                    sdot += __shfl_xor(sdot, 32);
+                    const double lg = m0 + log_pos(sdot);
+                    const bool mine = dq == 0 && dw < nw;
+                    const double cw = crow[t0 + (dw < nw ? dw : 0)];
+                    part += mine ? cw * lg : 0.0;
+                    STM_WAVE_SYNC();                 // (1)'s reads of wrow are done
+                    if (mine) wrow[t0 + dw] = cw / sdot;
+                    STM_WAVE_SYNC();
+#pragma unroll 4
+                    for (int w = 0; w < nw; ++w) {   // (3)
+                        const double wq = wrow[t0 + w];
+#pragma unroll
+                        for (int r = 0; r < VPL; ++r)
+                            if (lane + WAVE * r < KP) {
+                                const double bv = slab[(size_t)w * KP + lane + WAVE * r];
+                                va[r] = fma(bv, wq, va[r]);
+                            }
+                    }
+                    STM_WAVE_SYNC();
+                }
+#pragma unroll
+                for (int r = 0; r < VPL; ++r) {
+                    const int i = lane + WAVE * r;
+                    g0[r] = (i < n) ? g0a[r] : 0.0;
+                    vdat[r] = (i < K) ? va[r] * se[i] : 0.0;
+                }
+                part0 = wave_sum(part);
+                have0 = true;
+            }
+        }
+        // the first evaluation of f after that sweep: everything but the data term
+        auto eval_F0 = [&]() __attribute__((always_inline)) -> double {
+            double m, ssum, e_lane = 0.0;
+            int icnt;
+            head_F(m, icnt, ssum, e_lane);
+            STM_WAVE_SYNC();
+            const double lse = lse_F(m, icnt, ssum);
+            const double q = quad_F();
+            STM_WAVE_SYNC();
+            return 0.5 * q - (part0 - Ndoc * lse);
         };
 
         // rows [i0, i1) of column j of the BFGS update  H <- H - rho (s w^T + w s^T) + cc s s^T  (see S_ACCEPT2).
@@ -1395,7 +1463,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     if (need_g) dval = dot(gv, p);
                 } else {
                     if (need_f) {
-                        if (!f_ok) { cache_f = eval_F(); f_ok = true; ++nfev; }
+                        if (!f_ok) { cache_f = (DIRECT && have0 && st == S_INIT_DONE) ? eval_F0() : eval_F(); f_ok = true; ++nfev; }
                         fval = cache_f;
                     }
                     if (need_g) {
@@ -1486,7 +1554,20 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     if (MOM && cuts && mproof && k == 0 && derphi0 < 0.0 && range > 0.0) {
                         mvar0 = var0;
                         want_mom = true;
-                        if (NW == 1) {
+                        if (DIRECT && have0) {   // the sums came with the set-up sweep
+                            double t1 = 0.0;
+#pragma unroll
+                            for (int r = 0; r < VPL; ++r) t1 += vdat[r] * ((lane + WAVE * r < n) ? p[r] : 0.0);
+                            const double D1 = wave_sum(t1), am = D1 / Ndoc;
+                            double t2 = 0.0;
+#pragma unroll
+                            for (int r = 0; r < VPL; ++r) {
+                                const double dv = ((lane + WAVE * r < n) ? p[r] : 0.0) - am;
+                                t2 += vdat[r] * (dv * dv);
+                            }
+                            mD1 = D1; mD2 = py_max2(0.0, wave_sum(t2)) * (1.0 + 1e-9); mg0p = dot(g0, p);
+                            mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);
+                        } else if (NW == 1) {
                             // one-wave forms: the pass runs at the loop's evaluation site (like an evaluation, nothing of this block
                             // is live across it); its operands go through the LDS.  (Two-wave form: done with the first evaluation.)
                             mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);   // (before sv is an operand)
@@ -1505,7 +1586,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 st = S_W1_START;
                 if (MOM && want_mom) {
                     st = S_MOMENTS;
-                    if (NW == 1) break;      // through the loop top for the pass
+                    if (NW == 1 && !(DIRECT && have0)) break;      // through the loop top for the pass
                     want_mom = false;        // two-wave form: straight to the verdict
                 }
             } [[fallthrough]];
