@@ -16,6 +16,7 @@
 #include "stm_betass.h"
 #include "stm_post.h"
 #include "stm_post_big.h"
+#include "stm_post_big2.h"
 #include "stm_solver.h"
 
 namespace {
@@ -153,6 +154,7 @@ struct stm_handle {
     size_t red_len = 0;
     bool dma = false;            // two-wave solver with LDS-staged row gather (K == KREG = 50 or 64)
     bool direct = false;         // K > 64: rows re-gathered from betaT per pass instead of a per-document slab
+    bool big2 = false;           // 64 < K <= 112: the two-waves-per-document post kernel (stm_post_big2.h) + the word-major beta_ss pass
     // optional dumps
     double *d_phi = nullptr;
     int64_t phi_doc = -1;
@@ -562,7 +564,8 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = dalloc(&h->d_pd, N)) return rc;
     if (int rc = dalloc(&h->d_counters, 8)) return rc;
     if (int rc = dalloc(&h->d_err, 1)) return rc;
-    if (K <= stm::PT) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (the K > 64 kernels add phi atomically)
+    h->big2 = stm::post2_serves(K) && env_int("STM_POST_BIG2", 1) != 0;
+    if (K <= stm::PT || h->big2) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (post_big_kernel adds phi atomically)
     // one block (one wave) per document.  The solver keeps beta_d on chip (64 words in registers,
     // the rest in LDS); launches are cut so every launch has one LDS size / occupancy class.
     if (int rc = plan_solver(h)) return rc;
@@ -717,8 +720,10 @@ static int bss_enqueue(stm_handle *h) {
     HIP_TRY(hipEventRecord(h->ev_b[2 * h->bss_pair], h->stream));
     // even K: two rows per load instruction (needs 16-byte aligned rows and N K 8 < 4 GiB for its 32-bit offsets)
     const bool two = (K % 2 == 0) && (size_t)h->N * K * 8 < ((size_t)1 << 32) && env_int("STM_BETASS_TWO", 1) != 0;
-    if (two) hipLaunchKernelGGL((stm::beta_ss_part2_kernel<8, stm::BETASS_ROWS>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
-    else hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+    if (two && K <= 64) hipLaunchKernelGGL((stm::beta_ss_part2_kernel<8, stm::BETASS_ROWS, 2>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+    else if (two) hipLaunchKernelGGL((stm::beta_ss_part2_kernel<8, stm::BETASS_ROWS, 1>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+    else if (K <= 64) hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS, 1>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
+    else hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS, 2>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
     hipLaunchKernelGGL(stm::beta_ss_reduce_kernel, dim3((unsigned)((bp.R * K + 255) / 256)), dim3(256), 0, h->stream, bp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_b[2 * h->bss_pair + 1], h->stream));
@@ -769,8 +774,9 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-    // (post_big_kernel adds phi atomically; the K <= 64 word-major pass writes every cell of beta_ss)
-    if (K > 64 || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
+    // (post_big_kernel adds phi atomically; the word-major pass writes every cell of beta_ss)
+    const bool wm = K <= stm::PT || h->big2;
+    if (!wm || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
     // last document's phi is what the reference leaves in self.phi (stm.py:1116)
     h->phi_doc = h->N - 1;
     if (h->N > 0) {
@@ -840,18 +846,28 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
                      : (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, false>
                         : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
         }
-        const bool big = K > stm::PT;   // two topics per lane (stm_post_big.h)
-        rem_used = rem && !big;
+        const bool big2 = h->big2;                  // two waves per document (stm_post_big2.h)
+        const bool big = K > stm::PT && !big2;      // one wave per document, two topics per lane (stm_post_big.h): K > 112
+        rem_used = rem && K <= stm::PT;
         pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
         const int nbb = (n + 15) / 16;
         const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
                            : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
-        const PostFn pfn = big ? pfb : pf;
-        const size_t lds = (big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
+        PostFn pf2 = nullptr;
+        const int pc2 = stm::post2_pc(K);
+        if (big2) {
+            if (pc2 == 40) pf2 = dbg ? (nbb <= 4 ? stm::post_big2_kernel<4, 40, true> : stm::post_big2_kernel<5, 40, true>)
+                                     : (nbb <= 4 ? stm::post_big2_kernel<4, 40, false> : stm::post_big2_kernel<5, 40, false>);
+            else pf2 = dbg ? (nbb <= 5 ? stm::post_big2_kernel<5, 56, true> : nbb == 6 ? stm::post_big2_kernel<6, 56, true> : stm::post_big2_kernel<7, 56, true>)
+                           : (nbb <= 5 ? stm::post_big2_kernel<5, 56, false> : nbb == 6 ? stm::post_big2_kernel<6, 56, false> : stm::post_big2_kernel<7, 56, false>);
+        }
+        const PostFn pfn = big2 ? pf2 : big ? pfb : pf;
+        const unsigned wg_threads = big2 ? 128u : 64u;
+        const size_t lds = (big2 ? (size_t)stm::post2_lds_map(K, pc2).total : big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
         pp.lds_doubles = (int)(lds / sizeof(double));
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, 64, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, (int)wg_threads, lds));
         per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 16)));
         const int64_t grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
         if (big) {   // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
@@ -859,20 +875,20 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
             pp.a_scratch = h->d_ascratch;
         }
         pp.first = 0; pp.count = h->N;
-        // nu is summed per workgroup in a slab of its own (post_kernel: plain read-modify-write, nrep = grid) or
+        // nu is summed per workgroup in a slab of its own (post_kernel, post_big2_kernel: plain read-modify-write, nrep = grid) or
         // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
         nrep = big ? h->nrep : (int)grid;
         const int nbc = (n + 15) / 16;
-        // post_kernel: accumulator-tile layout; with REM the last column has a slot of its own instead of a block column of tiles
+        // accumulator-tile layout; with REM (post_kernel) the last column has a slot of its own instead of a block column of tiles
         slab = big ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
         if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
         HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
         pp.sigma_part = h->d_sigma_part; pp.nrep = nrep;
         pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
-        hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(64), lds, h->stream, pp);
+        hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(wg_threads), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        if (!big && h->nnz > 0) {
+        if (wm && h->nnz > 0) {
             if (defer_bss) h->bss_deferred = true;     // the caller enqueues it behind its read-back
             else if (int rc = bss_enqueue(h)) return rc;
         }
@@ -949,7 +965,7 @@ int stm_debug_get_mats(stm_handle *h, double *hess, double *chol, double *nu) {
 int stm_last_kernel_ms(stm_handle *h, float *ms3) {
     if (!h || !ms3) return fail(STM_ERR_INVALID, "null argument");
     bss_time(h);   // (a deferred pass may still be running: then its last completed time stands in -- it does not vary)
-    ms3[0] = h->ms[0]; ms3[1] = h->ms[1] + (h->K <= 64 ? h->ms_bss : 0.0f); ms3[2] = h->ms[2];
+    ms3[0] = h->ms[0]; ms3[1] = h->ms[1] + ((h->K <= 64 || h->big2) ? h->ms_bss : 0.0f); ms3[2] = h->ms[2];
     return STM_OK;
 }
 int stm_synchronize(stm_handle *h) {

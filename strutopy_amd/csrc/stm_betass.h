@@ -38,7 +38,8 @@ constexpr int BETASS_ROWS = 4;                // rows per wave (2 / 4 / 8 / 16 r
 
 // One wave per (ROWS rows, group), lane = topic; blockIdx is group-major.  A cell's (document, r) pairs are fetched
 // lane-parallel -- the next cell's while the current one is consumed -- and handed out with v_readlane, DEPTH theta rows in flight.
-template <int DEPTH, int ROWS>
+// TPL: topics per lane (2 for 64 < K <= 128: topics lane and lane + 64).
+template <int DEPTH, int ROWS, int TPL = 1>
 __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
     const int lane = threadIdx.x & 63;
     const int K = P.K, G = P.G;
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
     const int64_t wv = (blockIdx.x % bpg) * 4 + (threadIdx.x >> 6);
     if (wv >= wpg) return;
     const int64_t r0 = wv * ROWS, r1 = r0 + ROWS < R ? r0 + ROWS : R;
-    const int kl = lane < K ? lane : 0;
-    const double *th0 = P.theta + kl;
+    const int kl = lane < K ? lane : 0, kl1 = lane + WAVE < K ? lane + WAVE : 0;
+    const double *th0 = P.theta + kl, *th1 = P.theta + kl1;
     // lane q <= rows: the cell boundaries cp[(r0 + q) * G + g] and, in the next lane block, their ends
     const int nr = (int)(r1 - r0);
     const int lo_l = lane < nr ? P.cptr[(r0 + lane) * G + g] : 0, hi_l = lane < nr ? P.cptr[(r0 + lane) * G + g + 1] : 0;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
     int dl, dn = 0;
     double rl, rn = 0.0;
     fetch(e0, e1, dl, rl);
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0};
     while (q < nr) {
         const int cnt = e1 - e0 < WAVE ? e1 - e0 : WAVE;
         // the batch after this one: the rest of the cell, or the next row's cell
@@ -76,20 +77,26 @@ __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
         }
         if (nq < nr) fetch(n0, n1, dn, rn);
         for (int u = 0; u < cnt; u += DEPTH) {   // DEPTH loads all the same: the entries beyond cnt carry r = 0
-            double th[DEPTH], r[DEPTH];
+            double th[DEPTH], tg[DEPTH], r[DEPTH];
 #pragma unroll
             for (int t = 0; t < DEPTH; ++t) {
                 const int ut = (u + t) & (WAVE - 1);
                 const int d = __builtin_amdgcn_readlane(dl, ut);
                 th[t] = th0[(size_t)d * K];
+                if (TPL == 2) tg[t] = th1[(size_t)d * K];
                 r[t] = lane_bcast(rl, ut);
             }
 #pragma unroll
-            for (int t = 0; t < DEPTH; ++t) acc[t & 3] = fma(th[t], r[t], acc[t & 3]);
+            for (int t = 0; t < DEPTH; ++t) {
+                acc[t & 3] = fma(th[t], r[t], acc[t & 3]);
+                if (TPL == 2) acc1[t & 3] = fma(tg[t], r[t], acc1[t & 3]);
+            }
         }
         if (nq != q) {   // the cell is complete
             if (lane < K) P.part[((size_t)g * R + (size_t)(r0 + q)) * K + lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            if (TPL == 2 && lane + WAVE < K) P.part[((size_t)g * R + (size_t)(r0 + q)) * K + lane + WAVE] = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
             acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+            acc1[0] = acc1[1] = acc1[2] = acc1[3] = 0.0;
         }
         q = nq; e0 = n0; e1 = n1; dl = dn; rl = rn;
     }
@@ -99,7 +106,8 @@ __global__ __launch_bounds__(256) void beta_ss_part_kernel(BetaSsParams P) {
 // 0 .. K/2-1 serve the even entries of a batch and lanes K/2 .. K-1 the odd ones: half the memory instructions (each moves 2 x 8K
 // bytes), half the FMAs' instruction count, twice the rows in flight per wave for the same DEPTH -- the pass is bound by how many
 // gathers the CU keeps in the air.  A cell's sum is (even entries) + (odd entries), each in four round-robin partial sums.
-template <int DEPTH, int ROWS>
+// RPI = 1 (64 < K <= 128, even): a row is more than 32 pieces, one theta row per load instruction (lanes 0 .. K/2-1).
+template <int DEPTH, int ROWS, int RPI = 2>
 __global__ __launch_bounds__(256) void beta_ss_part2_kernel(BetaSsParams P) {
     const int lane = threadIdx.x & 63;
     const int K = P.K, G = P.G, CH = K >> 1;
@@ -109,8 +117,8 @@ __global__ __launch_bounds__(256) void beta_ss_part2_kernel(BetaSsParams P) {
     const int64_t wv = (blockIdx.x % bpg) * 4 + (threadIdx.x >> 6);
     if (wv >= wpg) return;
     const int64_t r0 = wv * ROWS, r1 = r0 + ROWS < R ? r0 + ROWS : R;
-    const int rr = lane >= CH ? 1 : 0, cc = lane - rr * CH;
-    const bool act = lane < 2 * CH;
+    const int rr = (RPI == 2 && lane >= CH) ? 1 : 0, cc = lane - rr * CH;
+    const bool act = lane < RPI * CH;
     const unsigned coff = 16u * (unsigned)(act ? cc : 0);
     const char *th0 = reinterpret_cast<const char *>(P.theta);
     const unsigned K8 = 8u * (unsigned)K;
@@ -139,12 +147,12 @@ __global__ __launch_bounds__(256) void beta_ss_part2_kernel(BetaSsParams P) {
         if (nq < nr) fetch(n0, n1, dn, rn);
         const unsigned doff = (unsigned)dl * K8;             // (N K 8 < 4 GiB: checked by the host)
         const int rlo = __double2loint(rl), rhi = __double2hiint(rl);
-        for (int u = 0; u < cnt; u += 2 * DEPTH) {          // DEPTH loads = 2 DEPTH entries; the entries beyond cnt carry r = 0
+        for (int u = 0; u < cnt; u += RPI * DEPTH) {        // DEPTH loads = RPI DEPTH entries; the entries beyond cnt carry r = 0
             double2 th[DEPTH];
             double r[DEPTH];
 #pragma unroll
             for (int t = 0; t < DEPTH; ++t) {
-                const int src = 4 * ((u + 2 * t + rr) & (WAVE - 1));
+                const int src = 4 * ((u + RPI * t + rr) & (WAVE - 1));
                 const unsigned o = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)doff) + coff;
                 th[t] = *reinterpret_cast<const double2 *>(th0 + o);
                 r[t] = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, rhi), __builtin_amdgcn_ds_bpermute(src, rlo));
@@ -157,11 +165,13 @@ __global__ __launch_bounds__(256) void beta_ss_part2_kernel(BetaSsParams P) {
         }
         if (nq != q) {   // the cell is complete: even-entry lanes add their odd-entry partners' sums
             double sx = (ax[0] + ax[1]) + (ax[2] + ax[3]), sy = (ay[0] + ay[1]) + (ay[2] + ay[3]);
-            const int partner = 4 * (lane + CH < WAVE ? lane + CH : lane);
-            const double ox = __hiloint2double(__builtin_amdgcn_ds_bpermute(partner, __double2hiint(sx)), __builtin_amdgcn_ds_bpermute(partner, __double2loint(sx)));
-            const double oy = __hiloint2double(__builtin_amdgcn_ds_bpermute(partner, __double2hiint(sy)), __builtin_amdgcn_ds_bpermute(partner, __double2loint(sy)));
+            if (RPI == 2) {
+                const int partner = 4 * (lane + CH < WAVE ? lane + CH : lane);
+                sx += __hiloint2double(__builtin_amdgcn_ds_bpermute(partner, __double2hiint(sx)), __builtin_amdgcn_ds_bpermute(partner, __double2loint(sx)));
+                sy += __hiloint2double(__builtin_amdgcn_ds_bpermute(partner, __double2hiint(sy)), __builtin_amdgcn_ds_bpermute(partner, __double2loint(sy)));
+            }
             if (lane < CH)
-                *reinterpret_cast<double2 *>(P.part + ((size_t)g * R + (size_t)(r0 + q)) * K + 2 * lane) = make_double2(sx + ox, sy + oy);
+                *reinterpret_cast<double2 *>(P.part + ((size_t)g * R + (size_t)(r0 + q)) * K + 2 * lane) = make_double2(sx, sy);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { ax[t] = 0.0; ay[t] = 0.0; }
         }

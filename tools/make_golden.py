@@ -246,9 +246,9 @@ def case_k50_v10k():
          K=np.int32(K), V=np.int32(V), sample_cols=cols, beta0_cols=beta0_cols, **out)
 
 
-def case_wiki_k50():
+def _wiki_case(K, name, teacher_forced_beta=False, corpus_ref=None):
     """src/03_fit_reference_model.py:40-74 config on the shipped wiki BoW corpus; EM its 0-1.
-    ELBO[0] is pinned by the shipped src/artifacts/reference_model/50/lower_bound.pickle."""
+    ELBO[0] is pinned by the shipped src/artifacts/reference_model/<K>/lower_bound.pickle."""
     import pickle
 
     import pandas as pd
@@ -263,18 +263,41 @@ def case_wiki_k50():
     data = pd.read_csv(os.path.join(art, "wiki_data", "corpus_preproc.csv"))
     xmat = np.array(data.loc[:, ["statistics"]])
     dictionary = {i: str(i) for i in range(M.shape[1])}
-    shipped = pickle.load(open(os.path.join(art, "reference_model", "50", "lower_bound.pickle"), "rb"))
-    K = 50
+    shipped = pickle.load(open(os.path.join(art, "reference_model", str(K), "lower_bound.pickle"), "rb"))
     np.random.seed(12345)
     m = make_model(docs, dictionary, K, xmat, max_em_iter=25)
     V = M.shape[1]
     cols = np.linspace(0, V - 1, 64).astype(np.int64)
+    if teacher_forced_beta:   # the beta entering EM iteration 1 in full (the HIP path is teacher-forced there)
+        beta_in = {}
+        orig = m.M_step
+
+        def m_step(beta_ss, sigma_ss):
+            orig(beta_ss, sigma_ss)
+            beta_in[len(beta_in) + 1] = np.asarray(m.beta).copy()
+        m.M_step = m_step
     out = run_em(m, 2, keep_beta_ss="summary", sample_cols=cols)
+    if teacher_forced_beta:
+        out["it1_beta_in"] = beta_in[1]
     print("    shipped ELBO[0:2] =", shipped[0], shipped[1])
-    indptr, idx, cnt = docs_to_csr(docs)
-    save("wiki_k50", indptr=indptr, indices=idx, counts=cnt, X=np.asarray(xmat, dtype=np.float64),
+    if corpus_ref:   # the corpus lives in another fixture (same .mm file)
+        corpus = dict(corpus=np.asarray(corpus_ref))
+    else:
+        indptr, idx, cnt = docs_to_csr(docs)
+        corpus = dict(indptr=indptr, indices=idx, counts=cnt)
+    save(name, X=np.asarray(xmat, dtype=np.float64),
          K=np.int32(K), V=np.int32(V), sample_cols=cols,
-         shipped_lower_bound=np.asarray(shipped, dtype=np.float64), **out)
+         shipped_lower_bound=np.asarray(shipped, dtype=np.float64), **corpus, **out)
+
+
+def case_wiki_k50():
+    _wiki_case(50, "wiki_k50")
+
+
+def case_wiki_k70():
+    """The second of the two numbers the reference ships for this path: K = 70 on the wiki corpus
+    (src/artifacts/reference_model/70/lower_bound.pickle[0] = -868098.47); takes the K > 64 kernels on real data."""
+    _wiki_case(70, "wiki_k70", teacher_forced_beta=True, corpus_ref="wiki_k50")
 
 
 def case_content_a2():
@@ -616,7 +639,7 @@ def case_mstep_modes():
 
 CASES = dict(mstep_modes=case_mstep_modes, toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
-             wiki_k50=case_wiki_k50, k50_late=case_k50_late, spectral_c1=case_spectral_c1, k100_v5k=case_k100_v5k, content_k50=case_content_k50,
+             wiki_k50=case_wiki_k50, wiki_k70=case_wiki_k70, k50_late=case_k50_late, spectral_c1=case_spectral_c1, k100_v5k=case_k100_v5k, content_k50=case_content_k50,
              spectral_wiki=case_spectral_wiki)
 
 if __name__ == "__main__":
