@@ -566,6 +566,13 @@ static int bfgs_minimize(doc_t *d, double *x, int *nit_out, double *fun_out) {
 /* Hessian, PD fix, Cholesky, nu, bound, phi                           */
 /* ------------------------------------------------------------------ */
 #define STM_PIVOT_TOL (32.0 * 2.220446049250313e-16)
+/* Smallest |pivot| / diagonal entry over every pivot test since it was last reset (all rungs of the PD ladder, the
+ * failing pivot of a failed attempt included): how far the document stays from the STM_PIVOT_TOL band, where this
+ * restatement (and the kernels) would deviate from np.linalg.cholesky's "pivot <= 0". */
+static double g_pivot_margin = 1e300;
+#ifdef _OPENMP
+#pragma omp threadprivate(g_pivot_margin)
+#endif
 /* np.linalg.cholesky (lower).  Returns 0 on success, 1 when not PD. L's upper part is zeroed. */
 static int chol_lower(int n, const double *A, double *L) {
     for (size_t i = 0; i < (size_t)n * n; ++i) L[i] = 0.0;
@@ -576,6 +583,10 @@ static int chol_lower(int n, const double *A, double *L) {
          * produce an EXACTLY singular matrix (n = 2: [[|o|, o], [o, |o|]], every time both diagonals are raised), and
          * there the sign of the pivot -- like the sign of the smallest eigenvalue the reference tests -- is decided
          * by the last bit of the input; "failed" leads to the + 1e-5 branch instead of a factor with a 1e-8 pivot. */
+        {
+            const double ratio = fabs(dsum) / fabs(A[(size_t)j * n + j]);   /* NaN / 0-diagonal: recorded as 0 */
+            if (!(ratio >= g_pivot_margin)) g_pivot_margin = (ratio == ratio) ? ratio : 0.0;
+        }
         if (!(dsum > STM_PIVOT_TOL * A[(size_t)j * n + j])) return 1;
         double ljj = sqrt(dsum);
         L[(size_t)j * n + j] = ljj;
@@ -897,10 +908,12 @@ int stm_oracle_estep(const stm_oracle_args *a, int nthreads) {
                 th[K - 1] = exp(0.0); s += th[K - 1];
                 for (int k = 0; k < K; ++k) th[k] /= s;
             }
+            g_pivot_margin = 1e300;
             int path = hessian_pd(&d, eta, Hm, Lm, wK); /* stm.py:553 */
             if (a->pd_path) a->pd_path[i] = path;
             if (a->hess_out) memcpy(a->hess_out + (size_t)i * n * n, Hm, sizeof(double) * (size_t)n * n);
             int dp = stm_oracle_decompose(n, Hm, Lm, nu); /* stm.py:556, 568 */
+            if (a->pivot_margin) a->pivot_margin[i] = g_pivot_margin;
             if (dp < 0) {
 #ifdef _OPENMP
 #pragma omp critical

@@ -26,6 +26,7 @@ class _Args(C.Structure):
         ("theta", _dp), ("bound", _dp), ("sigma_ss", _dp), ("beta_ss", _dp), ("bound_total", _dp),
         ("status", _ip), ("nit", _ip), ("nfev", _ip), ("njev", _ip), ("pd_path", _ip),
         ("hess_out", _dp), ("chol_out", _dp), ("nu_out", _dp), ("phi_last", _dp),
+        ("pivot_margin", _dp),
     ]
 
 
@@ -125,6 +126,8 @@ def estep(indptr, indices, counts, beta, mu, eta, siginv, sigmaentropy, aspect=N
             out[k] = np.zeros((N, n, n))
             setattr(a, f, _d(out[k]))
     a.phi_last = _d(phi_last)
+    out["pivot_margin"] = np.zeros(N)
+    a.pivot_margin = _d(out["pivot_margin"])
     rc = lib().stm_oracle_estep(C.byref(a), int(nthreads))
     if rc != 0:
         msg = lib().stm_oracle_last_error().decode()

@@ -60,7 +60,7 @@ def shard_bounds(indptr, world):
 
 # ------------------------------------------------------------------------------ host groups
 # Wire format of the host group.  Nothing received is ever unpickled: a frame is an 8-byte length (capped) and a body in
-# the small tagged encoding below (None, bool, int, float, str, bytes, list, tuple, dict, ndarray), and a connection is
+# the small tagged encoding below (None, bool, int, float, str, bytes, list, tuple, dict, ndarray; object arrays element by element), and a connection is
 # only used after both ends have proved, with an HMAC over a fresh nonce, that they hold the run's shared secret
 # (STM_RDZV_SECRET from the launcher, or a 0600 file in a 0700 directory owned by this user).
 _MAGIC = b"STMRDZV2"
@@ -88,11 +88,21 @@ def _enc(obj, out):
     elif isinstance(obj, dict):
         out.append(b"M" + struct.pack("<Q", len(obj)))
         for k, v in obj.items():
-            _enc(str(k), out)
+            if not (k is None or isinstance(k, (bool, np.bool_, int, np.integer, float, np.floating, str, bytes))):
+                raise TypeError(f"host group: a dict key of type {type(k).__name__} cannot be sent")
+            _enc(k, out)    # keys keep their type ({1: 2} does not come back as {'1': 2})
             _enc(v, out)
+    elif isinstance(obj, np.ndarray) and obj.dtype.hasobject:
+        # what pandas hands over for string / categorical columns: the elements go one by one through this same tagged
+        # encoding (scalars only -- None, bool, int, float, str, bytes), never as a serialised Python object
+        if obj.dtype != object:
+            raise TypeError("host group: structured arrays with object fields are not sent")
+        out.append(b"O" + struct.pack("<B", obj.ndim) + struct.pack(f"<{obj.ndim}q", *obj.shape))
+        for x in obj.ravel():
+            if not (x is None or isinstance(x, (bool, np.bool_, int, np.integer, float, np.floating, str, bytes, bytearray))):
+                raise TypeError(f"host group: an object array holding {type(x).__name__} cannot be sent")
+            _enc(x, out)
     elif isinstance(obj, np.ndarray):
-        if obj.dtype.hasobject:
-            raise TypeError("host group: object arrays are not sent")
         a = np.ascontiguousarray(obj)
         dt = a.dtype.str.encode("ascii")
         out.append(b"A" + struct.pack("<BB", len(dt), a.ndim) + dt + struct.pack(f"<{a.ndim}q", *a.shape))
@@ -139,6 +149,26 @@ def _dec(buf, pos):
         if tag == b"U":
             return tuple(items), pos
         return dict(zip(items[0::2], items[1::2])), pos
+    if tag == b"O":
+        (nd,) = struct.unpack_from("<B", buf, pos)
+        pos += 1
+        if nd > 8:
+            raise ValueError("host group: bad array header")
+        shape = struct.unpack_from(f"<{nd}q", buf, pos)
+        pos += 8 * nd
+        cnt = 1
+        for d in shape:
+            if d < 0:
+                raise ValueError("host group: bad array shape")
+            cnt *= d
+        if cnt > len(buf) - pos:          # every element takes at least its tag byte
+            raise ValueError("host group: truncated frame")
+        arr = np.empty(cnt, dtype=object)
+        for q in range(cnt):
+            if buf[pos:pos + 1] not in (b"N", b"T", b"F", b"I", b"D", b"S", b"B"):
+                raise ValueError("host group: an object array holds scalars only")
+            arr[q], pos = _dec(buf, pos)
+        return arr.reshape(shape), pos
     if tag == b"A":
         ld, nd = struct.unpack_from("<BB", buf, pos)
         pos += 2

@@ -64,11 +64,16 @@ def _covariate(g, xkind):
     if xkind == "binary":
         return g["X"][:, 0]
     N = len(g["indptr"]) - 1
-    return np.minimum(np.arange(N) * 3 // max(N - 40, 1), 2)
+    lev = np.minimum(np.arange(N) * 3 // max(N - 40, 1), 2)
+    if xkind == "pandas_str":   # a string column of a DataFrame: .to_numpy() hands over an object array
+        import pandas as pd
+        return pd.DataFrame({"field": np.array(["arts", "maths", "stats"], dtype=object)[lev]})
+    return lev
 
 
 @pytest.mark.parametrize("case,model_type,group,xkind", [("c1_k10", "STM", "gloo", "binary"), ("toy_ctm", "CTM", "gloo", "binary"),
-                                                         ("c1_k10", "STM", "tcp", "binary"), ("c1_k10", "STM", "tcp", "sorted3")])
+                                                         ("c1_k10", "STM", "tcp", "binary"), ("c1_k10", "STM", "tcp", "sorted3"),
+                                                         ("c1_k10", "STM", "tcp", "pandas_str")])
 def test_two_rank_fit_equals_single_process(case, model_type, group, xkind):
     import torch.multiprocessing as mp
     from _oracle_engine import OracleEngine
@@ -196,12 +201,21 @@ def test_tcp_group_survives_garbage_and_rejects_the_wrong_secret():
 def test_host_group_wire_format_round_trips_without_pickle():
     from strutopy_amd import dist as sdist
     obj = (1, -2.5, True, None, "x", b"\x00\xff", [np.arange(6, dtype=np.int32).reshape(2, 3), np.array(["a", "bc"])],
-           {"k": (np.float64(3.0), np.int64(7))})
+           {"k": (np.float64(3.0), np.int64(7)), 1: 2, None: "n"})
     back = sdist._decode(sdist._encode(obj))
     assert back[:6] == obj[:6] and np.array_equal(back[6][0], obj[6][0]) and back[6][0].dtype == np.int32
-    assert np.array_equal(back[6][1], obj[6][1]) and back[7] == {"k": (3.0, 7)}
+    assert np.array_equal(back[6][1], obj[6][1]) and back[7] == {"k": (3.0, 7), 1: 2, None: "n"}   # keys keep their type
+    oa = np.array([["arts", None, 3], ["x", 2.5, True]], dtype=object)      # what pandas gives for string / mixed columns
+    ob = sdist._decode(sdist._encode(oa))
+    assert ob.dtype == object and ob.shape == oa.shape and ob.tolist() == oa.tolist()
     with pytest.raises(TypeError):
         sdist._encode(object())
+    with pytest.raises(TypeError):
+        sdist._encode(np.array([object()], dtype=object))         # scalars only inside an object array
+    with pytest.raises(TypeError):
+        sdist._encode({(1, 2): 3})                                  # no silent str() of keys
+    with pytest.raises(ValueError):
+        sdist._decode(b"O\x01" + struct_pack_q(1) + b"L" + struct_pack_q(0))   # ... and on the way in
     with pytest.raises(ValueError):
         sdist._decode(b"A\x03\x01|O8" + struct_pack_q(1))          # an object-dtype array header is refused
     assert "pickle" not in open(sdist.__file__).read().replace("no pickle", "").replace("unpickled", "")

@@ -192,6 +192,52 @@ def test_k100_kernels_against_the_reference_itself():
         _against_reference(d, g, p, f"k100 it{it}")
 
 
+def test_wiki_k70_known_answer_and_teacher_forced_iteration():
+    """wiki corpus at K = 70 (real data, N_d ~ 60, the K > 64 kernels): EM iteration 0 against the number the reference ships
+    (src/artifacts/reference_model/70/lower_bound.pickle[0] = -868098.47) and both iterations against the reference run of
+    tests/golden/wiki_k70.npz, iteration 1 teacher-forced with the reference's beta."""
+    from strutopy_amd.engine import estep_host
+    g = load_golden("wiki_k70")
+    c = load_golden(str(g["corpus"]))
+    shipped = float(g["shipped_lower_bound"][0])
+    for it, beta in ((0, reference_beta0(70, int(g["V"]))), (1, g["it1_beta_in"])):
+        p = f"it{it}_"
+        d = estep_host(c["indptr"], c["indices"], c["counts"], beta, g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                       float(g[p + "sigmaentropy"]))
+        _against_reference(d, g, p, f"wiki k70 it{it}")
+        assert _rel(d["beta_ss"][:, g["sample_cols"]], g[p + "beta_ss_cols"]) <= 1e-8
+        assert np.max(np.abs(d["theta"] - g[p + "theta"])) <= 1e-7
+        if it == 0:
+            assert abs(d["bound"] - shipped) <= 1e-9 * abs(shipped)
+
+
+@pytest.mark.parametrize("K", [70, 100])
+def test_k_above_64_statistics_are_run_to_run_identical(K):
+    """64 < K <= 112 (post_big2_kernel): no atomics on the data path -- r_dw + the word-major beta_ss pass, nu in per-workgroup
+    slabs, fixed-order reductions -- so beta_ss, sigma_ss and the bound of two E-steps on the same state agree bit for bit."""
+    from strutopy_amd.corpus import synthetic_corpus
+    from strutopy_amd.engine import HipEstepEngine
+    c = synthetic_corpus(3000, 4000, K, n_words=120, seed=K).corpus
+    beta = reference_beta0(K, c.V)
+    n = K - 1
+    rng = np.random.default_rng(K)
+    eta0 = rng.normal(0, 0.2, size=(c.N, n))
+    siginv = np.eye(n) / 20.0
+    sigent = 0.5 * n * np.log(20.0)
+    runs = []
+    for _ in range(2):
+        e = HipEstepEngine(0)
+        e.set_corpus(c.indptr, c.indices, c.counts, c.V)
+        e.set_topics(K)
+        e.put_beta(beta); e.put_mu(np.zeros((c.N, n))); e.put_eta(eta0)
+        bound = e.estep(siginv, sigent)
+        runs.append((bound, e.get_beta_ss(), e.get_sigma_ss(), e.get_eta()))
+        e.close()
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        assert np.array_equal(a, b)
+
+
 def test_content_covariate_at_k50_against_the_reference_itself():
     """BASELINE config 4's shape (K = 50, A = 2) against the reference: E-steps teacher-forced, then the resident loop's
     device M-step for per-level beta (beta_normalise_topics_kernel) against the reference's M-step results."""

@@ -129,6 +129,62 @@ def test_wiki_known_answer_shipped_by_reference(oracle):
     assert abs(o["bound"] - shipped) <= 1e-10 * abs(shipped)
 
 
+def test_wiki_k70_known_answer_and_teacher_forced_iteration(oracle):
+    """The second of the two numbers the reference ships for this path: wiki corpus at K = 70,
+    src/artifacts/reference_model/70/lower_bound.pickle[0] = -868098.47 (producer src/03_fit_reference_model.py:40-74).
+    K = 70 is a K > 64 shape on real data (N_d ~ 60); EM iteration 1 is teacher-forced with the reference's own beta."""
+    g = load_golden("wiki_k70")
+    c = load_golden(str(g["corpus"]))
+    shipped = float(g["shipped_lower_bound"][0])
+    assert abs(shipped - (-868098.47)) < 0.01
+    for it, beta in ((0, reference_beta0(70, int(g["V"]))), (1, g["it1_beta_in"])):
+        p = f"it{it}_"
+        o = oracle.estep(c["indptr"], c["indices"], c["counts"], beta, g[p + "mu_in"], g[p + "eta_in"],
+                         g[p + "siginv"], float(g[p + "sigmaentropy"]), nthreads=0)
+        _check_against_reference(o, g, p, f"wiki k70 it{it}")
+        assert _rel(o["beta_ss"][:, g["sample_cols"]], g[p + "beta_ss_cols"]) <= 1e-8
+        if it == 0:
+            assert abs(o["bound"] - shipped) <= 1e-10 * abs(shipped)
+
+
+def test_pivot_tolerance_band_is_inert_on_baseline_shapes(oracle):
+    """PIVOT_TOL (a Cholesky pivot below 32 ulp of its diagonal entry counts as failed: oracle chol_lower, kernels
+    stm_post_common.h) is the one deliberate deviation from stm.py:1017-1021 / np.linalg.cholesky's "pivot <= 0" shared by
+    the oracle and the kernels.  On every BASELINE shape no pivot of any rung of any document's PD ladder -- accepted or
+    rejected -- comes within 1e3 x that band: the deviation cannot have changed an outcome there."""
+    from strutopy_amd.corpus import synthetic_corpus
+    band = 1e3 * 32.0 * 2.220446049250313e-16
+    worst = {}
+    g = load_golden("c2_full")                      # configs[1] at full size, EM iteration 0 (eta = mu = 0, the seeded beta)
+    K = int(g["K"])
+    c = synthetic_corpus(int(g["n_docs"]), int(g["V_requested"]), K, n_words=int(g["n_words"]), seed=int(g["seed"])).corpus
+    z = np.zeros((c.N, K - 1))
+    o = oracle.estep(c.indptr, c.indices, c.counts, reference_beta0(K, c.V), z, z, g["it0_siginv"], float(g["it0_sigmaentropy"]), nthreads=0)
+    assert np.array_equal(o["pd_path"], g["it0_pd_path"])
+    worst["c2_full it0"] = float(o["pivot_margin"].min())
+    for name, K in (("wiki_k50", 50), ("wiki_k70", 70)):
+        g = load_golden(name)
+        c = load_golden(str(g["corpus"])) if "corpus" in g.files else g
+        beta = reference_beta0(K, int(g["V"]))
+        for it in range(2):
+            p = f"it{it}_"
+            o = oracle.estep(c["indptr"], c["indices"], c["counts"], beta, g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
+                             float(g[p + "sigmaentropy"]), nthreads=0)
+            worst[f"{name} it{it}"] = float(o["pivot_margin"].min())
+            rs = o["beta_ss"].sum(axis=1)[:, None]
+            beta = g["it1_beta_in"] if "it1_beta_in" in g.files else np.divide(o["beta_ss"], rs, out=np.zeros_like(o["beta_ss"]), where=rs != 0)
+    g = load_golden("k100_v5k")
+    for it, p, args in _teacher_forced(g, 3, reference_beta0(100, int(g["V"]))):
+        worst[f"k100_v5k it{it}"] = float(oracle.estep(*args, nthreads=0)["pivot_margin"].min())
+    g = load_golden("k50_late")
+    for it in g["kept"]:
+        p = f"it{int(it)}_"
+        o = oracle.estep(g["indptr"], g["indices"], g["counts"], g[p + "beta_in"], g[p + "mu_in"], g[p + "eta_in"],
+                         g[p + "siginv"], float(g[p + "sigmaentropy"]), nthreads=0)
+        worst[f"k50_late it{int(it)}"] = float(o["pivot_margin"].min())
+    assert all(v > band for v in worst.values()), worst
+
+
 def test_toy_pipeline_final_bound(oracle):
     """tests/test_integration.py::_run_toy_pipeline of the reference: final_bound after 2 EM its."""
     g = load_golden("toy_ctm")
