@@ -180,6 +180,7 @@ struct stm_handle {
     int bss_pair = 0;
     bool bss_pair_used = false;
     bool bss_deferred = false;
+    bool last_deferred = false;   // the last E-step's pass was enqueued behind ev[3] (its time is added to 'estep' by stm_last_kernel_ms)
     float ms_bss = 0;
     float ms[3] = {0, 0, 0};
     bool beta_set = false;
@@ -469,6 +470,7 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     if (int rc = use_device(h)) return rc;
     const int64_t nnz = indptr[N] - indptr[0];
     if (indptr[0] != 0 || nnz < 0) return fail(STM_ERR_INVALID, "stm_set_corpus: indptr must start at 0 and be monotone");
+    if (nnz >= (int64_t)1 << 31) return fail(STM_ERR_INVALID, "stm_set_corpus: nnz must be < 2^31 per GPU shard (32-bit word-major slots)");
     if (nnz > 0 && (!indices || !counts)) return fail(STM_ERR_INVALID, "stm_set_corpus: indices/counts are NULL");
     int maxNd = 0;
     for (int64_t i = 0; i < N; ++i) {
@@ -520,7 +522,6 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     // word-major order (stm_betass.h): a counting sort of the CSR positions by (level, word, document chunk); documents
     // ascend within a row.  The chunk size is fixed when K is known (stm_set_topics); until then the entries are kept
     // on the host.
-    if (nnz >= (int64_t)1 << 31) return fail(STM_ERR_INVALID, "stm_set_corpus: nnz must be < 2^31 per GPU shard");
     h->h_indices.assign(indices, indices + nnz);
     if (aspect && A > 1) h->h_aspect.assign(aspect, aspect + N); else h->h_aspect.clear();
     if (int rc = dalloc(&h->d_rw, (size_t)nnz)) return rc;
@@ -534,9 +535,9 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (K < 2) return fail(STM_ERR_INVALID, "stm_set_topics: K must be >= 2");
     if (K > 128) return fail(STM_ERR_INVALID, "stm_set_topics: K > 128 is not supported by this build");
     if (int rc = use_device(h)) return rc;
+    if ((size_t)K * h->V * sizeof(double) >= ((size_t)1 << 32)) return fail(STM_ERR_INVALID, "stm_set_topics: one level of beta must stay below 4 GiB (32-bit row offsets)");
     h->K = K; h->n = K - 1;
     const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
-    if ((size_t)K * h->V * sizeof(double) >= ((size_t)1 << 32)) return fail(STM_ERR_INVALID, "stm_set_topics: one level of beta must stay below 4 GiB (32-bit row offsets)");
     if (int rc = dalloc(&h->d_betaT, KV + 64)) return rc;   // + 64: the kernels read whole 16-byte pieces / KREG <= 64 doubles from a row start, masked beyond K
     HIP_TRY(hipMemsetAsync(h->d_betaT + KV, 0, sizeof(double) * 64, h->stream));   // ... and what they mask must be finite
     // one packed buffer [ scalars(8) | sigma_ss | moments | beta_ss ] so a single all-reduce covers it
@@ -737,12 +738,7 @@ static void bss_time(stm_handle *h) {
         if (hipEventQuery(h->ev_b[2 * pr + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->ev_b[2 * pr], h->ev_b[2 * pr + 1]) == hipSuccess) { h->ms_bss = ms; return; }
         (void)hipGetLastError();
     }
-    if (h->ms_bss == 0.0f && h->bss_pair_used) {   // no pass has completed yet (the first E-step): wait for this one, once
-        float ms = 0;
-        if (hipEventSynchronize(h->ev_b[2 * h->bss_pair + 1]) == hipSuccess &&
-            hipEventElapsedTime(&ms, h->ev_b[2 * h->bss_pair], h->ev_b[2 * h->bss_pair + 1]) == hipSuccess) h->ms_bss = ms;
-        else (void)hipGetLastError();
-    }
+    // (no pass has completed yet -- the first fused iteration: 0 is reported rather than waiting for it here)
 }
 
 static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentropy, bool em_stage, bool defer_bss = false) {
@@ -761,8 +757,83 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         sig_bound = std::max(sig_bound, r);
     }
     const size_t KV = (size_t)h->A * K * h->V;
+    const bool wm = K <= stm::PT || h->big2;    // phi through r_dw + the word-major pass (post_big_kernel adds it atomically)
+    const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
+
+    // ---- (A) everything that can fail on the host -- sizes, device and pinned allocations, function attributes, the
+    // occupancy query -- BEFORE anything is enqueued: a rank of a multi-GPU fit that returned early between its first
+    // launch and the all-reduce would leave its peers waiting in the collective (stm_em_begin)
+    if (em_stage) if (int rc = ensure_pinned(h, &h->stage_sig, &h->stage_sig_cap, sizeof(double) * (size_t)n * n)) return rc;
+    // last document's phi is what the reference leaves in self.phi (stm.py:1116)
+    h->phi_doc = h->N - 1;
+    if (h->N > 0) {
+        const size_t nd = (size_t)(h->h_indptr[h->N] - h->h_indptr[h->N - 1]);
+        if (int rc = ensure(&h->d_phi, &h->phi_len, (size_t)K * nd)) return rc;
+    }
+    using PostFn = void (*)(stm::PostParams);
+    const bool run_post = (dbg_stage & 2) && h->N > 0;
+    const int post_debug = env_int("STM_POST_DEBUG", 0);
+    PostFn pfn = nullptr;
+    unsigned wg_threads = 64;
+    size_t lds = 0, slab = (size_t)n * n;
+    int64_t grid = 0;
+    int nrep = h->nrep;
+    bool rem_used = false;   // K <= 64 post kernel instantiated with REM = 1 (decides the layout of its nu slabs)
+    bool big = false;
+    if (run_post) {
+        // persistent workgroups: as many as the LDS / register budget keeps resident.  The matrix is n x n (n = K - 1):
+        // 16 x 16 MFMA blocks, and when n is one past a multiple of 16 (K = 50: 49 = 3 * 16 + 1) the last row / column
+        // of b b^T rides on the VALU instead of a padded block (post_kernel)
+        const bool rem = n > 16 && n % 16 == 1 && env_int("STM_POST_REM", 1);
+        const int nb = rem ? n / 16 : (n + 15) / 16;
+        const bool dbg = h->d_nu != nullptr || h->d_prof != nullptr || post_debug != 0;
+        PostFn pf;
+        if (rem) {
+            pf = dbg ? (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, true> : stm::post_kernel<3, 1, POST_WPE, true>)
+                     : (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, false> : stm::post_kernel<3, 1, POST_WPE, false>);
+        } else {
+            pf = dbg ? (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, true>
+                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, true> : stm::post_kernel<4, 0, 2, true>)
+                     : (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, false>
+                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
+        }
+        const bool big2 = h->big2;                  // two waves per document (stm_post_big2.h)
+        big = K > stm::PT && !big2;                 // one wave per document, two topics per lane (stm_post_big.h): K > 112
+        rem_used = rem && K <= stm::PT;
+        const int nbb = (n + 15) / 16;
+        const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
+                           : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
+        PostFn pf2 = nullptr;
+        const int pc2 = stm::post2_pc(K);
+        if (big2) {
+            if (pc2 == 40) pf2 = dbg ? (nbb <= 4 ? stm::post_big2_kernel<4, 40, true> : stm::post_big2_kernel<5, 40, true>)
+                                     : (nbb <= 4 ? stm::post_big2_kernel<4, 40, false> : stm::post_big2_kernel<5, 40, false>);
+            else pf2 = dbg ? (nbb <= 5 ? stm::post_big2_kernel<5, 56, true> : nbb == 6 ? stm::post_big2_kernel<6, 56, true> : stm::post_big2_kernel<7, 56, true>)
+                           : (nbb <= 5 ? stm::post_big2_kernel<5, 56, false> : nbb == 6 ? stm::post_big2_kernel<6, 56, false> : stm::post_big2_kernel<7, 56, false>);
+        }
+        pfn = big2 ? pf2 : big ? pfb : pf;
+        wg_threads = big2 ? 128u : 64u;
+        lds = (big2 ? (size_t)stm::post2_lds_map(K, pc2).total : big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, (int)wg_threads, lds));
+        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 16)));
+        grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
+        if (big)    // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
+            if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * n * n)) return rc;
+        // nu is summed per workgroup in a slab of its own (post_kernel, post_big2_kernel: plain read-modify-write, nrep = grid) or
+        // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
+        nrep = big ? h->nrep : (int)grid;
+        const int nbc = (n + 15) / 16;
+        // accumulator-tile layout; with REM (post_kernel) the last column has a slot of its own instead of a block column of tiles
+        slab = big ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
+        if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
+    }
+    // the first stage of the two-stage reductions + the bound's block sums (reduce_copies grows it otherwise)
+    if (int rc = ensure(&h->d_red, &h->red_len, (size_t)RED_Y * std::max(slab, (size_t)n * n) + BOUND_BLOCKS)) return rc;
+
+    // ---- (B) the E-step, enqueued on the handle's stream
     if (em_stage) {
-        if (int rc = ensure_pinned(h, &h->stage_sig, &h->stage_sig_cap, sizeof(double) * (size_t)n * n)) return rc;
         double *st = (double *)h->stage_sig;
         memcpy(st, siginv, sizeof(double) * (size_t)n * n);
         HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
@@ -774,15 +845,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
-    // (post_big_kernel adds phi atomically; the word-major pass writes every cell of beta_ss)
-    const bool wm = K <= stm::PT || h->big2;
-    if (!wm || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));
-    // last document's phi is what the reference leaves in self.phi (stm.py:1116)
-    h->phi_doc = h->N - 1;
-    if (h->N > 0) {
-        const size_t nd = (size_t)(h->h_indptr[h->N] - h->h_indptr[h->N - 1]);
-        if (int rc = ensure(&h->d_phi, &h->phi_len, (size_t)K * nd)) return rc;
-    }
+    if (!wm || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));   // (the word-major pass writes every cell)
 
     stm::SolverParams sp{};
     sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = h->KP; sp.zrow = (int)((int64_t)h->A * h->V);
@@ -799,17 +862,18 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     pp.indptr = h->d_indptr; pp.indices = h->d_indices; pp.counts = h->d_counts; pp.aspect = h->d_aspect;
     pp.betaT = h->d_betaT; pp.mu = h->d_mu; pp.eta = h->d_eta; pp.siginv = h->d_siginv; pp.siginv_diag = diag;
     pp.sigmaentropy = sigmaentropy; pp.theta = h->d_theta; pp.bound = h->d_bound; pp.beta_ssT = h->d_beta_ssT;
-    pp.sigma_part = h->d_sigma_part; pp.nrep = h->nrep; pp.order = h->d_order; pp.tick = h->d_tick;
+    pp.sigma_part = h->d_sigma_part; pp.nrep = nrep; pp.order = h->d_order; pp.tick = h->d_tick;
     pp.pd_path = h->d_pd; pp.err_flag = h->d_err;
     pp.hess_out = h->d_hess; pp.chol_out = h->d_chol; pp.nu_out = h->d_nu;
     pp.phi_doc = h->phi_doc; pp.phi_out = h->d_phi;
-    pp.debug_flags = env_int("STM_POST_DEBUG", 0);
+    pp.debug_flags = post_debug;
     pp.prof = h->d_prof;
+    pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
+    pp.lds_doubles = (int)(lds / sizeof(double));
+    pp.a_scratch = h->d_ascratch;
+    pp.first = 0; pp.count = h->N;
+    pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
 
-    const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
-    int nrep = h->nrep;
-    size_t slab = (size_t)h->n * h->n;
-    bool rem_used = false;   // K <= 64 post kernel instantiated with REM = 1 (decides the layout of its nu slabs)
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
@@ -828,67 +892,14 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
             }
         }
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    if ((dbg_stage & 2) && h->N > 0) {
-        // persistent single-wave workgroups: as many as the LDS / register budget keeps resident
-        using PostFn = void (*)(stm::PostParams);
-        // the matrix is n x n (n = K - 1): 16 x 16 MFMA blocks, and when n is one past a multiple of 16
-        // (K = 50: 49 = 3 * 16 + 1) the last row / column of b b^T rides on the VALU instead of a padded block
-        const bool rem = n > 16 && n % 16 == 1 && env_int("STM_POST_REM", 1);
-        const int nb = rem ? n / 16 : (n + 15) / 16;
-        const bool dbg = pp.nu_out != nullptr || pp.prof != nullptr || pp.debug_flags != 0;
-        PostFn pf;
-        if (rem) {
-            pf = dbg ? (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, true> : stm::post_kernel<3, 1, POST_WPE, true>)
-                     : (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, false> : stm::post_kernel<3, 1, POST_WPE, false>);
-        } else {
-            pf = dbg ? (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, true>
-                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, true> : stm::post_kernel<4, 0, 2, true>)
-                     : (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, false>
-                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
-        }
-        const bool big2 = h->big2;                  // two waves per document (stm_post_big2.h)
-        const bool big = K > stm::PT && !big2;      // one wave per document, two topics per lane (stm_post_big.h): K > 112
-        rem_used = rem && K <= stm::PT;
-        pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
-        const int nbb = (n + 15) / 16;
-        const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
-                           : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
-        PostFn pf2 = nullptr;
-        const int pc2 = stm::post2_pc(K);
-        if (big2) {
-            if (pc2 == 40) pf2 = dbg ? (nbb <= 4 ? stm::post_big2_kernel<4, 40, true> : stm::post_big2_kernel<5, 40, true>)
-                                     : (nbb <= 4 ? stm::post_big2_kernel<4, 40, false> : stm::post_big2_kernel<5, 40, false>);
-            else pf2 = dbg ? (nbb <= 5 ? stm::post_big2_kernel<5, 56, true> : nbb == 6 ? stm::post_big2_kernel<6, 56, true> : stm::post_big2_kernel<7, 56, true>)
-                           : (nbb <= 5 ? stm::post_big2_kernel<5, 56, false> : nbb == 6 ? stm::post_big2_kernel<6, 56, false> : stm::post_big2_kernel<7, 56, false>);
-        }
-        const PostFn pfn = big2 ? pf2 : big ? pfb : pf;
-        const unsigned wg_threads = big2 ? 128u : 64u;
-        const size_t lds = (big2 ? (size_t)stm::post2_lds_map(K, pc2).total : big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
-        pp.lds_doubles = (int)(lds / sizeof(double));
-        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, (int)wg_threads, lds));
-        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 16)));
-        const int64_t grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
-        if (big) {   // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
-            if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * n * n)) return rc;
-            pp.a_scratch = h->d_ascratch;
-        }
-        pp.first = 0; pp.count = h->N;
-        // nu is summed per workgroup in a slab of its own (post_kernel, post_big2_kernel: plain read-modify-write, nrep = grid) or
-        // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
-        nrep = big ? h->nrep : (int)grid;
-        const int nbc = (n + 15) / 16;
-        // accumulator-tile layout; with REM (post_kernel) the last column has a slot of its own instead of a block column of tiles
-        slab = big ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
-        if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
+    h->bss_deferred = false; h->last_deferred = false;
+    if (run_post) {
         HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
-        pp.sigma_part = h->d_sigma_part; pp.nrep = nrep;
-        pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
         hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(wg_threads), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
         if (wm && h->nnz > 0) {
+            h->last_deferred = defer_bss;
             if (defer_bss) h->bss_deferred = true;     // the caller enqueues it behind its read-back
             else if (int rc = bss_enqueue(h)) return rc;
         }
@@ -898,12 +909,11 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     if (slab == (size_t)n * n) {
         if (int rc = reduce_copies(h, h->d_sigma_part, nrep, n * n, h->d_sigma_ss)) return rc;
         hipLaunchKernelGGL(stm::mirror_blocks_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, h->d_sigma_ss, n);
-    } else {   // post_kernel's slabs: summed in their tile layout, then laid out as the matrix
+    } else {   // the slabs of post_kernel / post_big2_kernel: summed in their tile layout, then laid out as the matrix
         double *tiles = h->d_sigma_part + (size_t)nrep * slab;
         if (int rc = reduce_copies(h, h->d_sigma_part, nrep, (int)slab, tiles)) return rc;
         hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss, rem_used ? 1 : 0);
     }
-    if (int rc = ensure(&h->d_red, &h->red_len, (size_t)BOUND_BLOCKS)) return rc;   // (first BOUND_BLOCKS slots: the bound's block sums)
     hipLaunchKernelGGL(stm::bound_partial_kernel, dim3(BOUND_BLOCKS), dim3(256), 0, h->stream, (const double *)h->d_bound, h->N, h->d_red);
     hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, (const double *)h->d_red, (int64_t)BOUND_BLOCKS, h->d_scal, (const int32_t *)h->d_err);
     HIP_TRY(hipGetLastError());
@@ -964,8 +974,12 @@ int stm_debug_get_mats(stm_handle *h, double *hess, double *chol, double *nu) {
 
 int stm_last_kernel_ms(stm_handle *h, float *ms3) {
     if (!h || !ms3) return fail(STM_ERR_INVALID, "null argument");
-    bss_time(h);   // (a deferred pass may still be running: then its last completed time stands in -- it does not vary)
-    ms3[0] = h->ms[0]; ms3[1] = h->ms[1] + ((h->K <= 64 || h->big2) ? h->ms_bss : 0.0f); ms3[2] = h->ms[2];
+    // "post" = the post kernel + the beta_ss pass; "estep" = first to last kernel of the E-step.  A deferred pass (fused
+    // iteration) runs behind the E-step's last event and may still be in flight: the last COMPLETED pass stands in for it
+    // (its time does not vary from one iteration to the next), 0 before any has completed.
+    bss_time(h);
+    const float pass = (h->K <= 64 || h->big2) ? h->ms_bss : 0.0f;
+    ms3[0] = h->ms[0]; ms3[1] = h->ms[1] + pass; ms3[2] = h->ms[2] + (h->last_deferred ? pass : 0.0f);
     return STM_OK;
 }
 int stm_synchronize(stm_handle *h) {

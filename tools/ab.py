@@ -11,7 +11,7 @@ for setting in sys.argv[2:]:
             env[k] = v
     out = subprocess.run([sys.executable, "bench.py", "--cpu-sample", "0", "--late-sample", "0", *args], env=env, capture_output=True, text=True)
     try:
-        d = json.loads(out.stdout.strip().split("\n")[-1])
+        d = json.loads([l for l in out.stdout.split("\n") if l.startswith('{"metric')][-1])
         ps = d["per_step"]
         print(f"{setting:50s} ms/step {d['ms_per_step']:8.3f}  solver {sum(p['solver_kernel_ms'] for p in ps) / len(ps):7.3f}  post {sum(p['post_kernel_ms'] for p in ps) / len(ps):7.3f}  docs/s {d['value']:.4g}", flush=True)
     except Exception as e:
