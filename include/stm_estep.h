@@ -166,6 +166,18 @@ int stm_eval_heldout(stm_handle *h, int64_t N, const int64_t *indptr, const int3
 int stm_spectral_gram(stm_handle *h, int64_t N, int32_t Vk, const int64_t *doc_ptr, const int32_t *doc_word,
                       const double *doc_h, const int64_t *word_ptr, const int32_t *word_doc, const double *word_h,
                       const double *hhat);
+/* The same matrix from the handle's RESIDENT corpus (stm_set_corpus), restricted to the Vk distinct word ids keep[]
+ * (stm.py:50-58: the maxV most frequent terms): document lengths over the kept terms, the scaling and both
+ * orientations are formed by the library (a host counting sort of the CSR positions + device passes), nothing is
+ * prepared in NumPy.  The corpus may be one shard of a document-sharded fit -- gram is a sum over documents
+ * (stm.py:122-157): pass flags = 1 (no row-sum assert on the shard's own matrix), sum the shards' matrices with
+ * stm_spectral_allreduce (RCCL, in place on the device; a no-op without a communicator) or stm_spectral_get_q /
+ * stm_spectral_put_q (host reduction), then stm_spectral_check runs the reference's assert (stm.py:152-154) on the
+ * complete matrix.  Every rank then finds the same anchors and weights. */
+int stm_spectral_gram_resident(stm_handle *h, int32_t Vk, const int32_t *keep, int32_t flags);
+int stm_spectral_allreduce(stm_handle *h);
+int stm_spectral_put_q(stm_handle *h, const double *Q /* [Vk][Vk] */);
+int stm_spectral_check(stm_handle *h);
 /* rows of the matrix fastAnchor's caller holds: gram's result, after stm_spectral_anchors with the first
  * anchor's row rescaled (stm.py:185 modifies the caller's matrix in its first round) */
 int stm_spectral_get_q(stm_handle *h, const int32_t *rows, int32_t nrows, double *out /* [nrows][Vk] */);

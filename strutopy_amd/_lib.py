@@ -67,6 +67,10 @@ SIGNATURES = {
     "stm_em_finish": (C.c_int, [_h, _dp, _dp]),
     "stm_eval_heldout": (C.c_int, [_h, C.c_int64, _lp, _ip, _dp, _dp, _dp]),
     "stm_spectral_gram": (C.c_int, [_h, C.c_int64, C.c_int32, _lp, _ip, _dp, _lp, _ip, _dp, _dp]),
+    "stm_spectral_gram_resident": (C.c_int, [_h, C.c_int32, _ip, C.c_int32]),
+    "stm_spectral_allreduce": (C.c_int, [_h]),
+    "stm_spectral_put_q": (C.c_int, [_h, _dp]),
+    "stm_spectral_check": (C.c_int, [_h]),
     "stm_spectral_get_q": (C.c_int, [_h, _ip, C.c_int32, _dp]),
     "stm_spectral_anchors": (C.c_int, [_h, C.c_int32, _ip]),
     "stm_spectral_project": (C.c_int, [_h, C.c_int32, _ip, _dp]),

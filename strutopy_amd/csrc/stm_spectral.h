@@ -54,6 +54,70 @@ __global__ __launch_bounds__(256) void gram_kernel(const int64_t *doc_ptr, const
     if (threadIdx.x == 0 && !(part[0] > 0.0)) atomicMax(err_flag, 1);
 }
 
+// ---- gram on the handle's RESIDENT corpus (document shard): no host preparation of scaled orientations.
+// document length over the kept terms -> div[d] = n_d (n_d - 1) (stm.py:135-141), one wave per document
+__global__ __launch_bounds__(64) void gram_docdiv_kernel(const int64_t *indptr, const int32_t *indices, const double *counts,
+                                                         const int32_t *pos, int64_t N, double *div) {
+    const int64_t d = blockIdx.x;
+    if (d >= N) return;
+    double t = 0.0;
+    for (int64_t p = indptr[d] + threadIdx.x; p < indptr[d + 1]; p += 64) t += pos[indices[p]] >= 0 ? counts[p] : 0.0;   // counts are integers: exact in any order
+    t = wave_sum(t);
+    if (threadIdx.x == 0) div[d] = t * (t - 1.0);
+}
+// per CSR entry: kept-term id (or -1) and h = count / sqrt(n_d (n_d - 1)) (stm.py:142-146), one wave per document
+__global__ __launch_bounds__(64) void gram_scale_kernel(const int64_t *indptr, const int32_t *indices, const double *counts,
+                                                        const int32_t *pos, const double *div, int64_t N, int32_t *ent_j, double *ent_h) {
+    const int64_t d = blockIdx.x;
+    if (d >= N) return;
+    const double sq = sqrt(div[d]);
+    for (int64_t p = indptr[d] + threadIdx.x; p < indptr[d + 1]; p += 64) {
+        ent_j[p] = pos[indices[p]];
+        ent_h[p] = counts[p] / sq;
+    }
+}
+// gram_kernel over the resident CSR: word_q[e] is the CSR position of (document word_doc[e], kept term a), documents
+// ascending within a term.  Hhat[a] = sum_d count / (n_d (n_d - 1)) is summed along the way (thread 0, in document order).
+__global__ __launch_bounds__(256) void gram_resident_kernel(const int64_t *indptr, const int32_t *ent_j, const double *ent_h,
+                                                            const double *counts, const double *div, const int64_t *word_ptr,
+                                                            const int32_t *word_doc, const int32_t *word_q, int Vk, double *Q) {
+    extern __shared__ double grow[];
+    const int a = blockIdx.x;
+    for (int c = threadIdx.x; c < Vk; c += blockDim.x) grow[c] = 0.0;
+    __syncthreads();
+    const int64_t w0 = word_ptr[a], w1 = word_ptr[a + 1];
+    double hh = 0.0;
+    for (int64_t e = w0; e < w1; ++e) {
+        const int d = word_doc[e];
+        const int q = word_q[e];
+        const double ha = ent_h[q];
+        if (threadIdx.x == 0) hh += counts[q] / div[d];
+        const int64_t p0 = indptr[d], p1 = indptr[d + 1];
+        for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+            const int j = ent_j[p];
+            if (j >= 0) grow[j] += ha * ent_h[p];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) grow[a] -= hh;
+    __syncthreads();
+    for (int c = threadIdx.x; c < Vk; c += blockDim.x) Q[(size_t)a * Vk + c] = grow[c];
+}
+// assert np.all(Q.sum(axis=1) > 0) (stm.py:152-154) on the complete (all-reduced) matrix: one block per row, fixed-order sum
+__global__ __launch_bounds__(256) void gram_rowsum_check_kernel(const double *Q, int Vk, int32_t *err_flag) {
+    __shared__ double part[256];
+    const int a = blockIdx.x;
+    double t = 0.0;
+    for (int c = threadIdx.x; c < Vk; c += blockDim.x) t += Q[(size_t)a * Vk + c];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && !(part[0] > 0.0)) atomicMax(err_flag, 1);
+}
+
 // partial column sums of squares: part[blockIdx.y][c] = sum over the block's rows of Q[r][c]^2
 __global__ __launch_bounds__(256) void colsq_kernel(const double *Q, int Vk, double *part) {
     const int c = blockIdx.x * 256 + threadIdx.x;

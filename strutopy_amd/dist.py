@@ -429,6 +429,9 @@ class SingleComm:
     def allreduce_host(self, buf, op="sum"):
         return np.array(buf, dtype=np.float64, copy=True)
 
+    def spectral_reduce(self, engine):
+        pass
+
     def allgather(self, obj):
         return [obj]
 
@@ -474,6 +477,11 @@ class HostComm(_GroupComm):
     def allreduce_small(self, engine, buf):
         return self.group.allreduce(buf)
 
+    def spectral_reduce(self, engine):
+        """Sum of the shards' gram matrices (stm.py:122-157 is a sum over documents): pulled, reduced on the host, pushed back."""
+        Q = engine.spectral_q_rows(np.arange(engine.spectral_terms(), dtype=np.int32))
+        engine.spectral_put_q(self.group.allreduce(Q.ravel()).reshape(Q.shape))
+
 
 class RcclComm(_GroupComm):
     """RCCL all-reduce of the device-resident sufficient statistics (one per EM iteration)."""
@@ -489,3 +497,6 @@ class RcclComm(_GroupComm):
 
     def allreduce_small(self, engine, buf):
         return engine.allreduce_small(buf)
+
+    def spectral_reduce(self, engine):
+        engine.spectral_allreduce()     # the Vk x Vk matrix in place on the device (200 MB at maxV = 5000)

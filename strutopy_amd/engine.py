@@ -219,6 +219,27 @@ class HipEstepEngine:
                                         lptr(a["word_ptr"]), iptr(a["word_doc"]), dptr(a["word_h"]), dptr(f64(a["hhat"]))))
         self._Vk = int(Vk)
 
+    def spectral_gram_resident(self, keep, check=True):  # noqa: A002
+        """gram over the resident corpus (this rank's shard), restricted to the kept terms; check=False: the caller
+        sums the shards' matrices (spectral_allreduce / spectral_put_q) and then calls spectral_check."""
+        keep = np.ascontiguousarray(keep, dtype=np.int32)
+        _lib.check(self._L.stm_spectral_gram_resident(self._h, len(keep), iptr(keep), 0 if check else 1))
+        self._Vk = len(keep)
+
+    def spectral_terms(self):
+        return self._Vk
+
+    def spectral_allreduce(self):
+        check(self._L.stm_spectral_allreduce(self._h))
+
+    def spectral_put_q(self, Q):
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        assert Q.shape == (self._Vk, self._Vk)
+        check(self._L.stm_spectral_put_q(self._h, dptr(Q)))
+
+    def spectral_check(self):
+        check(self._L.stm_spectral_check(self._h))
+
     def spectral_q_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         out = np.empty((len(rows), self._Vk))

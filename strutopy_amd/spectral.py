@@ -22,10 +22,16 @@ import numpy as np
 from .corpus import pack_bow
 
 
-def kept_terms(corpus, maxV=5000):
-    """wprob and keep of stm.py:50-58.  create_dtm's csr_matrix has max(word id) + 1 columns."""
+def kept_terms(corpus, maxV=5000, comm=None):
+    """wprob and keep of stm.py:50-58.  create_dtm's csr_matrix has max(word id) + 1 columns.  With a multi-rank `comm`
+    the corpus is this rank's shard: the term totals (integers, exact in fp64 in any order) are summed over the shards, so
+    every rank -- like a single process on the whole corpus -- ranks the same numbers."""
     vmax = int(corpus.indices.max()) + 1
+    if comm is not None and comm.size > 1:
+        vmax = int(comm.allreduce_host(np.array([float(vmax)]), op="max")[0])
     tot = np.bincount(corpus.indices, weights=corpus.counts, minlength=vmax)
+    if comm is not None and comm.size > 1:
+        tot = comm.allreduce_host(tot)
     wprob = tot / np.sum(tot)
     keep = np.argsort(-1 * wprob)[:maxV]
     return wprob[keep], keep
@@ -33,7 +39,7 @@ def kept_terms(corpus, maxV=5000):
 
 def gram_inputs(corpus, keep):
     """The kept columns of the document-term matrix in both orientations, scaled as gram() scales them (stm.py:135-146)."""
-    vmax = int(corpus.indices.max()) + 1
+    vmax = max(int(corpus.indices.max()), int(np.max(keep))) + 1     # (a shard need not contain every kept term)
     pos = np.full(vmax, -1, dtype=np.int64)
     pos[keep] = np.arange(len(keep))
     col = pos[corpus.indices]
@@ -54,19 +60,35 @@ def gram_inputs(corpus, keep):
                 word_ptr=word_ptr, word_doc=doc[order].astype(np.int32), word_h=np.ascontiguousarray(h[order]), hhat=hhat)
 
 
-def spectral_init(corpus, K, V, maxV=5000, verbose=True, engine=None, details=None):
+def spectral_init(corpus, K, V, maxV=5000, verbose=True, engine=None, details=None, comm=None, resident=False):
     """Drop-in for spectral_init(corpus, K, V, maxV) (stm.py:30-85); `corpus` is the BoW list or a PackedCorpus,
-    `engine` a strutopy_amd.engine.HipEstepEngine (one is created on GPU 0 when omitted)."""
+    `engine` a strutopy_amd.engine.HipEstepEngine (one is created on GPU 0 when omitted).
+
+    resident: the engine already holds `corpus` (STM.__init__ has called set_corpus) -- gram then runs on the resident CSR
+    (stm_spectral_gram_resident: no NumPy preparation of the two scaled orientations).  comm: `corpus` is this rank's
+    shard of a document-sharded fit; gram is a sum over documents, so the shards' matrices are summed (one all-reduce of
+    Vk^2 doubles) and every rank finds the same anchors and the same beta."""
     corpus = pack_bow(corpus)
     own = engine is None
     if own:
         from .engine import HipEstepEngine
         engine = HipEstepEngine(0)
+    sharded = comm is not None and comm.size > 1
     try:
-        wprob, keep = kept_terms(corpus, maxV)
+        wprob, keep = kept_terms(corpus, maxV, comm)
         if verbose:
             print("Create gram matrix...")
-        engine.spectral_gram(corpus.N, len(keep), gram_inputs(corpus, keep))
+        if hasattr(engine, "spectral_gram_resident"):
+            if not resident:
+                engine.set_corpus(corpus.indptr, corpus.indices, corpus.counts, max(int(V), int(corpus.indices.max()) + 1))
+            engine.spectral_gram_resident(keep, check=not sharded)
+            if sharded:
+                comm.spectral_reduce(engine)
+                engine.spectral_check()
+        else:
+            if sharded:
+                raise NotImplementedError("this engine has no resident gram: a sharded spectral initialisation needs it")
+            engine.spectral_gram(corpus.N, len(keep), gram_inputs(corpus, keep))
         if verbose:
             print("Find anchor words...")
         anchor = engine.spectral_anchors(K)

@@ -193,12 +193,11 @@ class STM:
 
     def init_beta(self):
         if self.init == "spectral":
-            if self.comm.size > 1:
-                raise NotImplementedError("spectral initialisation needs the whole corpus on one rank: initialise once, "
-                                          "then hand beta to the sharded models")
             from .spectral import spectral_init
-            # stm.py:419-422; a 2-D beta also when kappa_interactions is set, like the reference
-            self.beta = spectral_init(self._corpus, self.K, self.V, maxV=5000, verbose=False, engine=self._engine)
+            # stm.py:419-422; a 2-D beta also when kappa_interactions is set, like the reference.  On a sharded fit every rank
+            # runs gram on its resident shard, the matrices are summed once, and all ranks end with the same beta.
+            self.beta = spectral_init(self._corpus, self.K, self.V, maxV=5000, verbose=False, engine=self._engine,
+                                      comm=self.comm, resident=True)
         elif self.init == "random":
             # stm.py:425-439, numpy legacy RNG stream seeded at stm.py:361
             beta_init = np.random.gamma(0.1, 1, self.V * self.K).reshape(self.K, self.V)

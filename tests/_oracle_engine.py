@@ -99,6 +99,28 @@ class OracleEngine:
         assert np.all(self._sq0.sum(axis=1) > 0), "Encountered zeroes in Q row sums, can not normalize."
         self._so = so
 
+    def spectral_gram_resident(self, keep, check=True):
+        """gram over this engine's own (shard of the) corpus, as stm_spectral_gram_resident: the oracle's NumPy restatement"""
+        from oracle import spectral_oracle as so
+        from strutopy_amd.corpus import PackedCorpus
+        from strutopy_amd.spectral import gram_inputs
+        c = PackedCorpus(self.indptr, self.indices, self.counts, self.V)
+        g = gram_inputs(c, np.asarray(keep))
+        Vk = len(keep)
+        D = np.zeros((c.N, Vk))
+        doc = np.repeat(np.arange(c.N), np.diff(g["doc_ptr"]))
+        D[doc, g["doc_word"]] = g["doc_h"]
+        self._sq0 = D.T @ D - np.diag(g["hhat"])
+        self._so = so
+        if check:
+            self.spectral_check()
+
+    def spectral_terms(self): return self._sq0.shape[0]
+    def spectral_put_q(self, Q): self._sq0 = np.array(Q, dtype=np.float64)
+
+    def spectral_check(self):
+        assert np.all(self._sq0.sum(axis=1) > 0), "Encountered zeroes in Q row sums, can not normalize."
+
     def spectral_anchors(self, K):
         anchor, self._sq0 = self._so.fast_anchor(self._sq0, K)
         return np.asarray(anchor, dtype=np.int32)

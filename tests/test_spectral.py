@@ -162,6 +162,49 @@ def test_device_gram_anchors_and_beta_match_the_reference(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_resident_gram_whole_and_sharded_against_the_prepared_orientations(name):
+    """stm_spectral_gram_resident (gram on the handle's resident CSR: no NumPy preparation) gives the matrix of stm_spectral_gram
+    fed with the prepared orientations -- the same products added in the same order, bit for bit -- and, run on two document
+    shards (flags = 1) whose matrices are then summed and pushed back, the reference's anchors again (gram is a sum over
+    documents, stm.py:122-157: how a sharded fit initialises)."""
+    from strutopy_amd.engine import HipEstepEngine
+    from strutopy_amd.spectral import gram_inputs, kept_terms
+    g = load_golden(name)
+    c = _corpus(g)
+    K, V = int(g["K"]), int(g["V"])
+    wprob, keep = kept_terms(c, 5000)
+    allrows = np.arange(len(keep), dtype=np.int32)
+    e = HipEstepEngine(0)
+    e.spectral_gram(c.N, len(keep), gram_inputs(c, keep))
+    q_prepared = e.spectral_q_rows(allrows)
+    e.set_corpus(c.indptr, c.indices, c.counts, V)
+    e.spectral_gram_resident(keep)
+    q_resident = e.spectral_q_rows(allrows)
+    assert np.array_equal(q_resident, q_prepared)
+    anchor_whole = e.spectral_anchors(K)
+    e.spectral_release()
+    # two shards, each on a handle of its own
+    mid = c.N // 2
+    parts = []
+    for lo, hi in ((0, mid), (mid, c.N)):
+        sh = c.slice(lo, hi)
+        es = HipEstepEngine(0)
+        es.set_corpus(sh.indptr, sh.indices, sh.counts, V)
+        es.spectral_gram_resident(keep, check=False)
+        parts.append(es.spectral_q_rows(allrows))
+        es.spectral_release(); es.close()
+    e.spectral_gram_resident(keep)                      # (allocates the state; its matrix is replaced by the shards' sum)
+    e.spectral_put_q(parts[0] + parts[1])
+    e.spectral_check()
+    assert np.allclose(parts[0] + parts[1], q_prepared, rtol=1e-12, atol=1e-13 * np.abs(q_prepared).max())
+    anchor = e.spectral_anchors(K)
+    assert np.array_equal(anchor, anchor_whole) and np.array_equal(anchor.astype(np.int64), g["anchor"].astype(np.int64))
+    e.spectral_release()
+    e.close()
+
+
+@pytest.mark.gpu
 def test_device_qp_with_a_dependent_anchor_row_is_still_a_minimiser():
     """Two identical anchor rows make P = M M^T singular: the passive-set factorisation of the second one fails, the column
     is banned (not re-factorised until the iteration cap) and the result must still satisfy the QP's KKT conditions -- a
