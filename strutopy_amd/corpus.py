@@ -13,6 +13,7 @@
   the dense N x V probability matrix (generate_docs.py:297), so it scales to the
   100k / 1M document configurations.
 """
+import os
 from dataclasses import dataclass
 from itertools import chain
 
@@ -57,33 +58,89 @@ class PackedCorpus:
         return np.bincount(self.indices, weights=self.counts, minlength=self.V)
 
 
+def _packbow_module():
+    """The C walker of the BoW lists (csrc/packbow.c, built in-tree by __graft_entry__.build); None when it is not built."""
+    try:
+        from . import _packbow
+        return _packbow
+    except ImportError:
+        return None
+
+
 def pack_bow(documents, V=None):
-    """list[list[(word_id, count)]] -> PackedCorpus, once (the reference rebuilds np.array(documents[i]) for
-    every document in every EM iteration, stm.py:522-533).  One pass of C-level iterators over the nested
-    sequences -- no per-document Python statement or NumPy call."""
+    """The corpus in any of the forms a caller may hold -> PackedCorpus, once (the reference rebuilds
+    np.array(documents[i]) for every document in every EM iteration, stm.py:522-533):
+
+    * list[list[(word_id, count)]] -- the reference's BoW lists (stm.py:311): one pass in C (csrc/packbow.c; an
+      iterator-based NumPy path when the helper is not built) -- no per-document Python statement or NumPy call
+    * a PackedCorpus, or the CSR triple (indptr, indices, counts) itself: validated, no copy of already-typed arrays
+    * a scipy.sparse matrix (documents x terms, what create_dtm builds, stm.py:87-119)
+    * a path to a MatrixMarket file (the format of the shipped src/artifacts/wiki_data/BoW_corpus.mm)
+    """
     if isinstance(documents, PackedCorpus):
         return documents
+    if isinstance(documents, (str, os.PathLike)):
+        c = read_mm(documents)
+        if V is not None and c.V < V:
+            c = PackedCorpus(c.indptr, c.indices, c.counts, int(V))
+        return _checked(c, V)
+    if hasattr(documents, "tocsr") and hasattr(documents, "shape"):      # scipy.sparse, documents x terms
+        m = documents.tocsr()
+        m.sum_duplicates(); m.sort_indices()
+        return _checked(PackedCorpus(m.indptr.astype(np.int64), m.indices.astype(np.int32), np.asarray(m.data, dtype=np.float64),
+                                     int(m.shape[1] if V is None else max(V, m.shape[1]))), V)
+    if isinstance(documents, (tuple, list)) and len(documents) == 3 and isinstance(documents[0], np.ndarray) and np.ndim(documents[0]) == 1 \
+            and isinstance(documents[1], np.ndarray) and isinstance(documents[2], np.ndarray):
+        indptr, indices, counts = documents
+        vmax = int(np.max(indices)) + 1 if len(indices) else 0
+        return _checked(PackedCorpus(np.ascontiguousarray(indptr, dtype=np.int64), np.ascontiguousarray(indices, dtype=np.int32),
+                                     np.ascontiguousarray(counts, dtype=np.float64), int(vmax if V is None else V)), V)
     N = len(documents)
-    lens = np.fromiter(map(len, documents), dtype=np.int64, count=N)
-    if N and lens.min() < 1:
-        raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
-    indptr = np.zeros(N + 1, dtype=np.int64)
-    np.cumsum(lens, out=indptr[1:])
-    nnz = int(indptr[-1])
-    try:
-        flat = np.fromiter(chain.from_iterable(chain.from_iterable(documents)), dtype=np.float64, count=2 * nnz)
-    except ValueError as e:   # an entry that is not a (word_id, count) pair
-        raise IndexError(f"documents must hold (word_id, count) pairs (stm.py:522-526): {e}") from None
-    indices = flat[0::2].astype(np.int32)
-    counts = np.ascontiguousarray(flat[1::2])
-    if nnz and (indices.min() < 0 or np.any(indices != flat[0::2])):
-        raise IndexError("word ids must be non-negative integers below 2^31")
-    vmax = int(indices.max()) + 1 if nnz else 0
+    pb = _packbow_module()
+    if pb is not None:
+        lens = np.zeros(N, dtype=np.int64)
+        nnz = int(pb.lengths(documents, lens))
+        indptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(lens, out=indptr[1:])
+        indices = np.empty(nnz, dtype=np.int32)
+        counts = np.empty(nnz, dtype=np.float64)
+        vmax = int(pb.fill(documents, indices, counts)) + 1
+    else:
+        lens = np.fromiter(map(len, documents), dtype=np.int64, count=N)
+        if N and lens.min() < 1:
+            raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
+        indptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(lens, out=indptr[1:])
+        nnz = int(indptr[-1])
+        try:
+            flat = np.fromiter(chain.from_iterable(chain.from_iterable(documents)), dtype=np.float64, count=2 * nnz)
+        except ValueError as e:   # an entry that is not a (word_id, count) pair
+            raise IndexError(f"documents must hold (word_id, count) pairs (stm.py:522-526): {e}") from None
+        indices = flat[0::2].astype(np.int32)
+        counts = np.ascontiguousarray(flat[1::2])
+        if nnz and (indices.min() < 0 or np.any(indices != flat[0::2])):
+            raise IndexError("word ids must be non-negative integers below 2^31")
+        vmax = int(indices.max()) + 1 if nnz else 0
     if V is None:
         V = vmax
     elif vmax > V:
         raise IndexError(f"word id {vmax - 1} is out of range for a dictionary of length {V}")
     return PackedCorpus(indptr, indices, counts, int(V))
+
+
+def _checked(c, V):
+    """A CSR corpus handed over as arrays: the checks pack_bow makes on the BoW lists."""
+    if len(c.indptr) < 1 or c.indptr[0] != 0 or (c.N and np.min(np.diff(c.indptr)) < 1):
+        raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
+    if len(c.indices) != int(c.indptr[-1]) or len(c.counts) != len(c.indices):
+        raise IndexError("indptr, indices and counts disagree")
+    if len(c.indices) and (int(c.indices.min()) < 0 or int(c.indices.max()) >= c.V):
+        raise IndexError(f"word id {int(c.indices.max())} is out of range for a dictionary of length {c.V}")
+    if V is not None and c.V > V:
+        if len(c.indices) and int(c.indices.max()) >= V:
+            raise IndexError(f"word id {int(c.indices.max())} is out of range for a dictionary of length {V}")
+        c = PackedCorpus(c.indptr, c.indices, c.counts, int(V))
+    return c
 
 
 def read_mm(path):

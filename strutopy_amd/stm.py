@@ -82,6 +82,9 @@ class STM:
         np.random.seed(123456)  # stm.py:361 reseeds numpy's legacy global RNG; kept for drop-in parity
         self.dtype = np.finfo(dtype).dtype
 
+        if not hasattr(documents, "__len__") or isinstance(documents, (str, tuple)) or hasattr(documents, "tocsr"):
+            # a MatrixMarket path, a scipy.sparse matrix or the CSR triple itself (corpus.pack_bow): packed here, once
+            documents = pack_bow(documents, V=len(dictionary) if dictionary is not None else None)
         self.documents = documents
         self.dictionary = dictionary
         self.init = init_type

@@ -150,6 +150,54 @@ def test_pack_bow_accepts_what_the_reference_accepts():
         pack_bow([[(-1, 1)]], V=10)
 
 
+def test_pack_bow_c_walker_and_iterator_path_agree(monkeypatch):
+    """csrc/packbow.c (built by __graft_entry__.build) and the iterator-based NumPy path: same arrays, same errors."""
+    import strutopy_amd.corpus as cm
+    if cm._packbow_module() is None:
+        pytest.skip("strutopy_amd/_packbow is not built")
+    big = synthetic_corpus(3000, 900, 5, n_words=80, seed=4).corpus
+    bow = big.to_bow()
+    bow[5] = [list(p) for p in bow[5]]                     # a document of lists
+    bow[6] = np.array(bow[6], dtype=np.float64)            # ... and one as an array, like np.array(documents[i]) takes them
+    fast = pack_bow(bow, V=big.V)
+    monkeypatch.setattr(cm, "_packbow_module", lambda: None)
+    slow = pack_bow(bow, V=big.V)
+    for a in ("indptr", "indices", "counts"):
+        assert np.array_equal(getattr(fast, a), getattr(slow, a)) and np.array_equal(getattr(fast, a), getattr(big, a))
+    monkeypatch.undo()
+    for bad in ([[(1, 1)], []], [[(1.5, 1)]], [[(-1, 1)]], [[(1, 1, 1)]], [[3]], [[(2 ** 31, 1)]]):
+        with pytest.raises(IndexError):
+            pack_bow(bad, V=10)
+    with pytest.raises(IndexError):
+        pack_bow([[(11, 1)]], V=10)
+
+
+def test_corpus_as_csr_triple_sparse_matrix_or_matrix_market_path(tmp_path):
+    """The forms a caller may already hold: the CSR triple, create_dtm's scipy matrix (stm.py:87-119) and a
+    MatrixMarket file go into STM(...) as they are -- no detour through lists of tuples."""
+    import scipy.sparse as sp
+    from scipy.io import mmwrite
+    from _oracle_engine import OracleEngine
+    from strutopy_amd.stm import STM
+    big = synthetic_corpus(400, 300, 4, n_words=40, seed=9)
+    m = sp.csr_matrix((big.corpus.counts, big.corpus.indices, big.corpus.indptr), shape=(big.corpus.N, big.corpus.V))
+    m.sort_indices()                                       # (a scipy matrix is taken in canonical form: word ids ascending)
+    c = PackedCorpus(m.indptr.astype(np.int64), m.indices.astype(np.int32), m.data.astype(np.float64), big.corpus.V)
+    path = tmp_path / "corpus.mm"
+    with open(path, "wb") as fh:
+        mmwrite(fh, m.tocoo())
+    for form in ((c.indptr, c.indices, c.counts), m, str(path), c.to_bow()):
+        p = pack_bow(form, V=c.V)
+        assert np.array_equal(p.indptr, c.indptr) and np.array_equal(p.indices, c.indices) and np.array_equal(p.counts, c.counts) and p.V == c.V
+        model = STM(documents=form, dictionary={i: str(i) for i in range(c.V)}, content=False, K=4, X=big.X, kappa_interactions=False,
+                    max_em_iter=1, sigma_prior=0, convergence_threshold=1e-5, init_type="random", engine=OracleEngine())
+        assert model.N == c.N and model.V == c.V
+    with pytest.raises(IndexError):
+        pack_bow((np.array([0, 1, 1]), np.array([2], dtype=np.int32), np.array([1.0])))         # an empty document
+    with pytest.raises(IndexError):
+        pack_bow((np.array([0, 1]), np.array([12], dtype=np.int32), np.array([1.0])), V=10)     # word id beyond the dictionary
+
+
 # ----------------------------------------------------------------------------- STM mirror
 def test_constructor_state_matches_reference_init():
     g = load_golden("toy_ctm")
