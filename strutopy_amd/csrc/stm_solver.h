@@ -1595,7 +1595,11 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 if (MOM && st == S_MOMENTS) {   // the verdict of the moment pass (see S_OUTER_TOP)
                     double b = py_min2(1.0, 1.01 * 2 * (phi0 - old_phi0) / derphi0);
                     if (b < 0) b = 1.0;
-                    const double range = prange, D2 = mD2, qx = mqx, g0p = mg0p, D1 = mD1;
+                    // D2 must be an UPPER bound of D''(0).  The word variances of the LDS / register forms are s2 / s0 - m1^2 on the raw
+                    // p~: where p~ is nearly constant over the topics a word loads on, the cancellation leaves an absolute error of
+                    // ~1e-16 N_d max|p~|^2 of either sign, which the relative allowances below do not cover -- max|p~| <= range (p~
+                    // contains a 0), so 64 ulp of N_d range^2 does.  (DIRECT bounds D2 by a mean square about a constant: no cancellation.)
+                    const double range = prange, D2 = mD2 + (DIRECT ? 0.0 : 1.5e-14 * (double)Ndoc * (double)prange * (double)prange), qx = mqx, g0p = mg0p, D1 = mD1;
                     const double slope0 = -derphi0, nv = Ndoc * mvar0;
                     const double a0 = ((derphi0 + g0p) - D1) + c1 * slope0, a0tol = 1e-9 * (slope0 + fabs(g0p) + fabs(D1));
                     bool dead = false;

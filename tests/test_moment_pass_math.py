@@ -52,7 +52,7 @@ def _verdict(x, mu, siginv, bd, c):
     S0, S1, S2 = e @ bd, (e * pt) @ bd, (e * pt * pt) @ bd
     m1 = S1 / S0
     D1 = float(c @ m1)
-    D2 = max(0.0, float(c @ (S2 / S0 - m1 * m1)))
+    D2 = max(0.0, float(c @ (S2 / S0 - m1 * m1))) + 1.5e-14 * N * rng_ * rng_   # + the absolute allowance for the cancellation
     g0p = float(g0[:-1] @ p)
     # first trial step of DCSRCH and wolfe2 at k = 0: old_old_fval = f0 + |g| / 2
     b = min(1.0, 1.01 * 2 * (-(np.linalg.norm(g) / 2)) / derphi0)
