@@ -6,9 +6,11 @@
 The two CSVs are separate rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`, `--kernel-trace --pmc WRITE_SIZE`: TCC counters, they do
 not fit one pass) of the SAME `bench.py --config X --steps S --warmup 0 --cpu-sample 0 --late-sample 0` command.  Dispatches are
 walked in order; an EM iteration starts with the first solver dispatch behind a post-kernel dispatch (tools/by_iteration.py).
-MI355X_MICROARCH.md (HBM section): bytes = (FETCH_SIZE + WRITE_SIZE) x 1024, and on gfx950 FETCH_SIZE under-reports coalesced
-reads by a pattern-dependent factor -- calibrated here on covariance_kernel, which streams eta exactly once per dispatch
-(N (K-1) 8 bytes, 8-B/lane coalesced loads); the factor is applied to every kernel's FETCH_SIZE and stored with the entry.
+MI355X_MICROARCH.md (HBM section): bytes = (FETCH_SIZE + WRITE_SIZE) x 1024, and on gfx950 FETCH_SIZE reports exactly 1/2 of the
+bytes of a wide coalesced streaming read (16 B/lane, global_load and LDS-DMA alike -- what the solver's and the post kernels' beta row
+fetches are): FETCH_SIZE is doubled, as the guide prescribes.  Cross-check stored with the entry: covariance_kernel streams eta
+exactly once per dispatch when K - 1 <= 64 (N (K-1) 8 bytes), which gives 1.989 on configs[1] and [4]; beyond 64 columns its
+blocks re-read column slices through the L2 and the check does not apply.
 The output holds ONE entry (this workload); tools/traffic_merge.py folds entries into profiles/hbm_traffic.json."""
 import collections, csv, json, sys
 
@@ -47,17 +49,19 @@ write, _ = per_iteration(wpath)
 n_it = min(len(fetch), len(write))
 cov_kb = sum(it.get("stm::covariance_kernel", 0.0) for it in fetch[:n_it])
 cov_n = ndisp.get("stm::covariance_kernel", 0)
-cal = (1.0 * docs * (topics - 1) * 8 * cov_n) / (cov_kb * 1024) if cov_kb else None
+check = (1.0 * docs * (topics - 1) * 8 * cov_n) / (cov_kb * 1024) if (cov_kb and topics - 1 <= 64) else None
+cal = 2.0
 entry = {"_workload": {"docs": docs, "vocab": vocab, "topics": topics, "words": words, "levels": levels},
          "_units": "bytes per EM iteration (all dispatches of the kernel in that iteration)", "_fetch_calibration": cal,
-         "_note": "FETCH_SIZE*1024*calibration + WRITE_SIZE*1024; calibration = known bytes of covariance_kernel / its FETCH_SIZE",
+         "_fetch_check_covariance_kernel": check,
+         "_note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE = half the bytes of 16-B/lane streams); check = known bytes of covariance_kernel / its FETCH_SIZE bytes",
          "_source": source, "iterations": {}}
 for i in range(n_it):
     ks = sorted(set(fetch[i]) | set(write[i]))
     entry["iterations"][str(i)] = {k: fetch[i].get(k, 0.0) * 1024 * (cal or 1.0) + write[i].get(k, 0.0) * 1024 for k in ks if k.startswith("stm::")}
     entry["iterations"][str(i)]["#raw_kb"] = {k: [fetch[i].get(k, 0.0), write[i].get(k, 0.0)] for k in ks if k.startswith("stm::")}
 json.dump(entry, open(out_path, "w"), indent=1)
-print(f"{n_it} EM iterations; fetch calibration {cal}")
+print(f"{n_it} EM iterations; fetch factor {cal} (covariance_kernel check: {check})")
 for i in sorted({0, 1, min(7, n_it - 1), n_it - 1}):
     it = entry["iterations"][str(i)]
     print(f"  EM it {i}: " + ", ".join(f"{k.replace('stm::', '')} {v / 1e9:.3f} GB" for k, v in it.items() if not k.startswith("#") and v > 5e7))
