@@ -645,57 +645,74 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             }
             STM_WG_SYNC();
             if (DBG && P.prof) ti[1] = (long long)__builtin_readcyclecounter();
-            // (II) X_rc = -X_rr (sum_{c<=k<r} L_rk X_kc) on the matrix cores, in place (X_rc takes the place of L_rc).  Block
-            //      (r, c) needs X_(r-1)c and overwrites what (r, c-1) reads: the anti-diagonals r + c = d of that grid are
-            //      independent, two blocks at a time (one per wave), a barrier between the rounds.  The inner sum comes out of
-            //      the MFMA in exactly the register layout its B operand wants, so it never visits the LDS.
+            // (II) X_rc = -X_rr (sum_{c<=k<r} L_rk X_kc) on the matrix cores.  The block columns of X are independent of each
+            //      other given L -- column c reads L_rk, k >= c, and its own X_kc -- so two columns are formed at a time, one
+            //      per wave, top down, and kept in REGISTERS: a finished X_kc leaves the MFMA in exactly the register layout
+            //      the B operand of the rows below wants, so it never visits the LDS, and nothing of L is overwritten while
+            //      either wave still reads it.  Both waves then store their column over L's (barrier before and after).
+            //      Three rounds at NB = 7; the longer column of a pair alternates between the waves.
+            {
+                v4d xcol[NB];
 #pragma unroll 1
-            for (int d = 1; d <= 2 * NB - 3; ++d) {
-                const int cmin = d - (NB - 1) > 0 ? d - (NB - 1) : 0, cmax = (d - 1) >> 1;   // c <= r - 1, r = d - c <= NB - 1
-                const int cnt = cmax - cmin + 1;
-#pragma unroll 1
-                for (int rd = 0; 2 * rd < cnt; ++rd) {
-                    const int qi = 2 * rd + wv;
-                    if (qi < cnt) {
-                        const int bj = cmin + qi, bi = d - bj;
-                        const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
-                        const double *arow = M + RS(arc);                     // row of L_i* / X_ii for the A operands
-                        const int bc = bj * 16 + fr;
-                        v4d sacc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-                        for (int k = bj; k < bi; ++k) {
-                            double av[4], bv[4];
+                for (int c0 = 0; c0 + 1 < NB; c0 += 2) {
+                    const int c = c0 + (wv ^ ((c0 >> 1) & 1));
+                    const int bc = c * 16 + fr;
+                    if (c + 1 < NB) {
 #pragma unroll
-                            for (int sk = 0; sk < 4; ++sk) {
-                                const int kk = k * 16 + 4 * sk + fq;           // < 16 (NB - 1) <= n: full blocks only
-                                av[sk] = arow[kk];                              // L_ik[fr][4 sk + fq]
-                                bv[sk] = M[RS(kk) + bc];                        // X_kj[4 sk + fq][fr]
+                        for (int r = 1; r < NB; ++r) {
+                            if (r > c) {   // uniform
+                                const int ar = r * 16 + fr, arc = ar < n ? ar : nm1;
+                                const double *arow = M + RS(arc);                     // row of L_r* / X_rr for the A operands
+                                v4d sacc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                                for (int k = 0; k < r; ++k) {
+                                    if (k >= c) {   // uniform
+                                        double av[4];
+#pragma unroll
+                                        for (int sk = 0; sk < 4; ++sk) av[sk] = arow[k * 16 + 4 * sk + fq];   // L_rk[fr][4 sk + fq] (k < NB - 1: full blocks)
+                                        if (k == c) {   // X_cc: the lower-triangular diagonal block, from the LDS
+                                            double bv[4];
+#pragma unroll
+                                            for (int sk = 0; sk < 4; ++sk) bv[sk] = M[RS(k * 16 + 4 * sk + fq) + bc];
+#pragma unroll
+                                            for (int sk = 0; sk < 4; ++sk) {
+                                                const int kk = k * 16 + 4 * sk + fq;
+                                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < n) ? av[sk] : 0.0, (bc <= kk) ? bv[sk] : 0.0, sacc, 0, 0, 0);
+                                            }
+                                        } else {
+#pragma unroll
+                                            for (int sk = 0; sk < 4; ++sk)
+                                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < n) ? av[sk] : 0.0, xcol[k][sk], sacc, 0, 0, 0);
+                                        }
+                                    }
+                                }
+                                double xv[4];
+#pragma unroll
+                                for (int sk = 0; sk < 4; ++sk) {
+                                    const int ac = r * 16 + 4 * sk + fq;
+                                    xv[sk] = arow[ac < arc ? ac : arc];                 // X_rr[fr][4 sk + fq], at most the diagonal cell
+                                }
+                                v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                                for (int sk = 0; sk < 4; ++sk) {
+                                    const int ac = r * 16 + 4 * sk + fq;
+                                    dacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ac <= ar && ar < n) ? xv[sk] : 0.0, sacc[sk], dacc, 0, 0, 0);
+                                }
+                                xcol[r] = -dacc;
                             }
+                        }
+                    }
+                    STM_WG_SYNC();   // both columns are complete: nobody reads L's columns c0, c0 + 1 below the diagonal blocks any more
+                    if (c + 1 < NB) {
 #pragma unroll
-                            for (int sk = 0; sk < 4; ++sk) {
-                                const int kk = k * 16 + 4 * sk + fq;
-                                const double a = (ar < n) ? av[sk] : 0.0;
-                                const double bb = (k > bj || bc <= kk) ? bv[sk] : 0.0;   // the diagonal block of X is lower triangular
-                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, sacc, 0, 0, 0);
+                        for (int r = 1; r < NB; ++r) {
+                            if (r > c) {   // uniform
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int row = r * 16 + fq + 4 * q;
+                                    M[row < n ? RS(row) + bc : MDUMP] = xcol[r][q];
+                                }
                             }
-                        }
-                        double xv[4];
-#pragma unroll
-                        for (int sk = 0; sk < 4; ++sk) {
-                            const int ac = bi * 16 + 4 * sk + fq;
-                            xv[sk] = arow[ac < arc ? ac : arc];                 // X_ii[fr][4 sk + fq], at most the diagonal cell
-                        }
-                        v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int sk = 0; sk < 4; ++sk) {
-                            const int ac = bi * 16 + 4 * sk + fq;
-                            const double a = (ac <= ar && ar < n) ? xv[sk] : 0.0;
-                            dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sacc[sk], dacc, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = bi * 16 + fq + 4 * r;
-                            M[row < n ? RS(row) + bc : MDUMP] = -dacc[r];
                         }
                     }
                     STM_WG_SYNC();
@@ -710,8 +727,8 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
         // nu = R R^T = X^T X (sigma_ss += nu, stm.py:582), one block column bj of output tiles (b <= bj) at a time on the
         // matrix cores, block columns dealt out to the waves: nu[i][j] = sum_{l >= 16 bj} X[l][i] X[l][j] (X is lower
         // triangular); fragment X[s4 + fq][b * 16 + fr], zero above the diagonal.  The workgroup's running sum lives in a slab
-        // of its own in the accumulators' register layout; its old values are fetched before the matrix-core loop they are
-        // added behind -- plain loads and stores, nobody else touches the slab.  Cells beyond n are exact zeros.
+        // of its own in the accumulators' register layout, added to with no-return atomics (a cell has ONE writer: its order of
+        // additions is the order of the workgroup's documents).  Cells beyond n are exact zeros.
         double *nu_doc = (DBG && P.nu_out) ? P.nu_out + (size_t)doc * n * n : nullptr;
         if (upper) {   // nu = diag(1 / L_ii^2): element (i, i) sits in tile (b, b) at r = ((i & 15) - fq) / 4, lane = (fq, fr = i & 15)
             for (int bb = wv; bb < NB; bb += 2) {
@@ -729,16 +746,9 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             for (int bj = wv; bj < NB; bj += 2) {
                 const int rj = bj * 16 + fr, rjc = rj < n ? rj : nm1;
                 double *slab = sig_acc + (size_t)(bj * (bj + 1) / 2) * 4 * WAVE + lane;
-                v4d an[NB], old[NB];
+                v4d an[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    an[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    old[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    if (b <= bj) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) old[b][r] = slab[(b * 4 + r) * WAVE];
-                    }
-                }
+                for (int b = 0; b < NB; ++b) an[b] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
                 for (int s4 = bj * 16; s4 < n; s4 += 4) {
                     const int col = s4 + fq, colc = col < n ? col : nm1;
@@ -760,7 +770,9 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                     if (b > bj) continue;   // uniform
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        slab[(b * 4 + r) * WAVE] = old[b][r] + an[b][r];
+                        // fire-and-forget: the cell belongs to this wave alone (no contention, program order from one document
+                        // to the next), so the sum is the same every run -- and no old value has to be fetched and held
+                        unsafeAtomicAdd(slab + (b * 4 + r) * WAVE, an[b][r]);
                         if (DBG && nu_doc) {
                             const int i = b * 16 + fq + 4 * r, j = rj;
                             if (i < n && j < n) {
