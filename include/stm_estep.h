@@ -51,11 +51,16 @@ int stm_device_info(stm_handle *h, char *name_out, int name_len, int *cu_count, 
 /* documents as CSR (the packed form of the reference's list-of-(id,count) BoW,
  * stm.py:522-533): indptr[N+1], indices[nnz] (unique within a document,
  * 0 <= id < V), counts[nnz] (integers stored as fp64), aspect[N] (level of the
- * content covariate per document, stm.py:527-528; NULL when A == 1). */
+ * content covariate per document, stm.py:527-528; NULL when A == 1).
+ * Limits per handle (one GPU's shard), checked before the handle is touched: N < 2^31, nnz < 2^31 (32-bit word-major
+ * slots), no empty document.  Besides the CSR arrays the handle keeps the corpus in word-major order for the atomics-free
+ * beta_ss pass (8 bytes per entry on the device + a host copy of indices[]) -- INTEGRATION.md lists the memory. */
 int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr,
                    const int32_t *indices, const double *counts, const int32_t *aspect, int32_t A);
 /* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467.  2 <= K <= 128 (K <= 64: one topic per
- * lane and the matrix-core post kernel; 64 < K <= 128: two topics per lane), STM_ERR_INVALID beyond */
+ * lane and the matrix-core post kernel; 64 < K <= 112: two topics per lane in the solver, two wavefronts per document
+ * in the post step; 112 < K <= 128: two topics per lane throughout), K * V * 8 < 2^32 per level of beta (32-bit row
+ * offsets): STM_ERR_INVALID beyond */
 int stm_set_topics(stm_handle *h, int32_t K);
 int stm_put_beta(stm_handle *h, const double *beta /* [A][K][V] */);
 int stm_put_eta(stm_handle *h, const double *eta /* [N][K-1] */);
@@ -119,7 +124,8 @@ int stm_put_covariates(stm_handle *h, const double *X, int32_t p);
  *   [ n_docs | sum_x (p) | sum_eta (K-1) | XtX (p*p) | Xt_eta (p*(K-1)) | eta^T eta ((K-1)^2) ]
  * (p = 0 without covariates: the CTM branch).  With gamma from the centred moments,
  * (eta - X gamma^T)^T (eta - X gamma^T) = eta^T eta - gamma Xt_eta - (gamma Xt_eta)^T + gamma XtX gamma^T,
- * so document shards exchange everything the M-step needs in ONE all-reduce. */
+ * so document shards exchange everything the M-step needs in one exchange per EM iteration (stm_em_begin sends it as two
+ * all-reduces: [scalars | sigma_ss | moments] in front of the host's read-back, beta_ss behind it). */
 int stm_mstep_moments(stm_handle *h, double *out, int64_t out_len);
 /* mu_d = x_d @ gamma^T (stm.py:706; gamma [(K-1)][p]) or, when gamma == NULL,
  * mu_d = mean_eta (CTM branch, stm.py:651; mean_eta [(K-1)]) */
@@ -133,13 +139,15 @@ int stm_mstep_update_beta(stm_handle *h);
 
 /* One EM iteration on resident state with ONE host wait (what STM.expectation_maximization runs):
  *   stm_em_begin   enqueues the E-step (as stm_estep), the moments (as stm_mstep_moments) and, when a communicator is
- *                  attached, the all-reduce of the packed buffer; waits once; returns the (reduced) bound, sigma_ss
- *                  and moments, and reports the E-step's errors like stm_estep.  Every fallible host-side step (sizes,
- *                  allocations) comes before anything is enqueued, and a rank's device error flag travels in slot 1 of
- *                  the packed scalars: with a communicator EVERY rank returns an error in the iteration in which any rank's
- *                  E-step failed.  Without a communicator the word-major beta_ss pass (K <= 64) is enqueued behind the
- *                  read-back and may still be running when the call returns; whatever touches beta_ss next on the handle
- *                  (stm_em_finish, stm_mstep_update_beta, stm_get_beta_ss, ...) is ordered behind it.
+ *                  attached, the all-reduce of [scalars | sigma_ss | moments] (the head of the packed buffer); waits once;
+ *                  returns the (reduced) bound, sigma_ss and moments, and reports the E-step's errors like stm_estep.  Every
+ *                  fallible host-side step (sizes, allocations, function attributes) comes before anything is enqueued, and
+ *                  a rank's device error flag travels in slot 1 of the packed scalars: with a communicator EVERY rank returns
+ *                  an error in the iteration in which any rank's E-step failed.  The word-major beta_ss pass (K <= 112) and,
+ *                  with a communicator, the all-reduce of beta_ss are enqueued BEHIND the read-back and may still be running
+ *                  when the call returns (the host's M-step algebra overlaps them); whatever touches beta_ss next on the
+ *                  handle (stm_em_finish, stm_mstep_update_beta, stm_get_beta_ss, ...) is ordered behind them.  Every rank
+ *                  enqueues the same two collectives in the same order.
  *   stm_em_finish  enqueues mu (regression on gamma, or the constant mean_eta when gamma == NULL) and beta from the
  *                  (reduced) beta_ss -- stm_mstep_set_mu + stm_mstep_update_beta without their waits; whatever is called
  *                  next on the handle is ordered behind them. */

@@ -190,9 +190,17 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             const double d = eta_i - mu_i;
             if (sdiag) {
                 if (isn) q = (d * S[(size_t)gl * n + gl]) * d;
-            } else if (isn) {
+            } else if (isn) {   // column gl of siginv from the L2, eight rows in flight; the sum keeps its order
                 double t = 0.0;
-                for (int j = 0; j < n; ++j) t += sdv[j] * S[(size_t)j * n + gl];
+                int j = 0;
+                for (; j + 7 < n; j += 8) {
+                    double sv8[8], dv8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { sv8[u] = S[(size_t)(j + u) * n + gl]; dv8[u] = sdv[j + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t += dv8[u] * sv8[u];
+                }
+                for (; j < n; ++j) t += sdv[j] * S[(size_t)j * n + gl];
                 q = t * d;
             }
             q = wave_sum(q);
