@@ -392,6 +392,9 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             // a pivot never exceeds its diagonal entry (what is subtracted from it are squares, in floating point too): an
             // entry <= 0 (or NaN) fails some pivot test for certain, and the attempt is decided without factorising
             if (wave_any(isn && !(diagA > 0.0))) return false;
+            // a pivot never exceeds its diagonal entry and a pivot that passes is above 32 eps of it: with the diagonal in
+            // the normal range every accepted pivot is, and the per-pivot range test of sqrt_and_rsqrt can go
+            const bool fast = !wave_any(isn && !(diagA > 1e-260 && diagA < 1e270));
             clean = false;
             if (isn) M[RS(lane) + lane] = diagA;
             STM_POST_SYNC();
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                         const double d = lane_bcast(tmp, J);
                         badl |= (lane == J) && !(tmp > PIVOT_TOL * diagA);   // see PIVOT_TOL
                         double ljj, rjj;                        // LAPACK dpotf2 scales the column by the reciprocal as well
-                        sqrt_and_rsqrt(d, ljj, rjj);
+                        if (fast) sqrt_and_rsqrt_pivot(d, ljj, rjj); else sqrt_and_rsqrt(d, ljj, rjj);   // (uniform)
                         if (lane == J) Ldiag = ljj;
                         if (j > 0) {   // the update with column J - 1 (stored at the end of the previous step), four broadcasts at a time
 #pragma unroll

@@ -66,7 +66,7 @@ __host__ __device__ inline Post2Lds post2_lds_map(int K, int PC) {
 __host__ __device__ inline int post2_pc(int K) { return K <= 80 ? 40 : 56; }
 __host__ __device__ inline bool post2_serves(int K) { return K > 64 && K <= 112; }
 
-enum { X_CSUM = 0, X_LL = 2, X_Q = 4, X_DET = 6, X_NEG = 8, X_BAD = 10 };
+enum { X_CSUM = 0, X_LL = 2, X_Q = 4, X_DET = 6, X_NEG = 8, X_BAD = 10, X_SLOW = 12 };
 
 template <int NB, int PC, bool DBG>
 __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
@@ -391,10 +391,12 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             // a pivot never exceeds its diagonal entry: an entry <= 0 (or NaN) fails some pivot test for certain, and the
             // attempt is decided without factorising.  (The diagonal cells of a clean M are not read again: diagA is.)
             const bool neg = wave_any(isn && !(diagA > 0.0));
-            if (lane == 0) xch[X_NEG + wv] = neg ? 1.0 : 0.0;
+            const bool slow = wave_any(isn && !(diagA > 1e-260 && diagA < 1e270));   // (see sqrt_and_rsqrt_pivot)
+            if (lane == 0) { xch[X_NEG + wv] = neg ? 1.0 : 0.0; xch[X_SLOW + wv] = slow ? 1.0 : 0.0; }
             if (isn) M[RS(gl) + gl] = diagA;
             STM_WG_SYNC();
             if (xch[X_NEG] != 0.0 || xch[X_NEG + 1] != 0.0) return false;
+            const bool fast = xch[X_SLOW] == 0.0 && xch[X_SLOW + 1] == 0.0;
             clean = false;
             bool ok = true;
 #pragma unroll 1
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                             const double d = lane_bcast(tmp, pl);
                             badl |= owner && (lane == pl) && !(tmp > PIVOT_TOL * diagA);   // see PIVOT_TOL
                             double ljj, rjj;                        // LAPACK dpotf2 scales the column by the reciprocal as well
-                            sqrt_and_rsqrt(d, ljj, rjj);
+                            if (fast) sqrt_and_rsqrt_pivot(d, ljj, rjj); else sqrt_and_rsqrt(d, ljj, rjj);   // (uniform)
                             if (owner && lane == pl) Ldiag = ljj;
                             if (j > 0) {   // the update with column J - 1 (stored at the end of the previous step), four broadcasts at a time
 #pragma unroll

@@ -130,6 +130,20 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double d, double &s, double &r) {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
 
+// The same pair for a Cholesky pivot whose range the caller has checked (every pivot that passes lies in (32 eps, 1] x its
+// diagonal entry, and the diagonal is tested once per attempt): no range test per pivot, and two coupled Goldschmidt steps
+// without the final corrections -- both results within ~2 ulp (the seed is good to 2^-23: 2^-46, then rounding), which is
+// what LAPACK's dpotf2 gets from sqrt and a division.
+__device__ __forceinline__ void sqrt_and_rsqrt_pivot(double d, double &s, double &r) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    s = g; r = h + h;
+}
+
 // ---- Python / numpy scalar semantics scipy's line searches rely on ----------------
 // builtin max/min keep the first argument unless a later one compares greater/less
 __device__ __forceinline__ double py_max2(double a, double b) { return (b > a) ? b : a; }
