@@ -13,7 +13,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 bad = 0
 for case in range(n_cases):
-    K = int(rng.choice([2, 3, 5, 10, 17, 33, 50, 64, 65, 100]))
+    K = int(rng.choice([2, 3, 5, 10, 17, 33, 50, 64, 65, 81, 100, 112, 120]))
     V = int(rng.integers(max(K, 60), 1500)); N = int(rng.integers(8, 300))
     lens = rng.integers(1, min(V, 120) + 1, size=N)
     docs = [np.sort(rng.choice(V, int(L), replace=False)) for L in lens]
