@@ -180,7 +180,7 @@ def _against_reference(d, g, p, tag):
 
 
 def test_k100_kernels_against_the_reference_itself():
-    """K = 100 (two topics per lane: solver_kernel<2,0,false,1,1> re-gathering beta rows per pass, post_big_kernel<7>) against
+    """K = 100 (two topics per lane: solver_kernel<2,0,false,1,1> re-gathering beta rows per pass; post_big2_kernel<7,56>: two waves per document) against
     three EM iterations of the REFERENCE (tests/golden/k100_v5k.npz), teacher-forced."""
     from strutopy_amd.engine import estep_host
     g = load_golden("k100_v5k")
@@ -513,6 +513,11 @@ def test_bench_launches_its_own_ranks_and_strong_scaling_shards_one_corpus():
     assert two["config"]["device_ordinals"] == [0, 0] and two["config"]["rccl_comm_count"] == [0] and two["config"]["allreduce"] == "tcp-host"
     for b in (one, two, weak):
         assert b["value"] == pytest.approx(b["config"]["docs_total"] * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"]), rel=1e-6)
+    # --gpus 1 --allreduce rccl: a real one-rank communicator, so the with-communicator iteration (small all-reduce, read-back,
+    # beta_ss pass + its all-reduce) is what runs -- same trace as without one
+    rc = run("--gpus", "1", "--scaling", "strong", "--allreduce", "rccl")
+    assert rc["config"]["allreduce"] == "rccl" and rc["config"]["rccl_comm_count"] == [1] and rc["config"]["allreduces_per_iteration"] == 2
+    assert np.allclose(rc["elbo_trace"], one["elbo_trace"], rtol=1e-12)
 
 
 def test_explicit_rccl_on_duplicate_devices_fails_cleanly():
