@@ -285,7 +285,7 @@ static int plan_solver(stm_handle *h) {
     const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
     const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
     h->KP = KP;
-    const size_t h_lds = h->nw == 2 ? (size_t)h->n * h->n * sizeof(double) : 0;  // BFGS matrix in LDS (two-wave form)
+    const size_t h_lds = h->nw == 2 ? ((size_t)h->n * h->n + (h->dma ? (size_t)stm::solver_dma_stage_extra(h->kreg, h->n) : 0)) * sizeof(double) : 0;  // BFGS matrix in LDS (two-wave form) + what the DMA staging needs beyond it
     // K > 64 (STM_SOLVER_K100 = "direct" unless set to 0): no copy of beta_d, one 16-word LDS tile re-gathered from betaT per pass
     h->direct = h->vpl == 2 && mode == 0 && env_int("STM_SOLVER_K100_DIRECT", 1) != 0;
     auto lds_of = [&](int nd) {

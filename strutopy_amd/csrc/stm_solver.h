@@ -74,6 +74,12 @@ struct SolverParams {
                             // [3] BFGS update, [8+st] cycles in state st (low 40 bits) and visits of it (bits 40..)
 };
 
+// doubles by which the two waves' DMA staging areas (32 rows of 2 ((KREG / 2) | 1) doubles each) reach beyond the BFGS matrix' n^2
+__host__ __device__ inline int solver_dma_stage_extra(int kreg, int n) {
+    const int need = 2 * 32 * 2 * ((kreg / 2) | 1);
+    return need > n * n ? need - n * n : 0;
+}
+
 enum : int {
     S_INIT_DONE = 0, S_OUTER_TOP, S_W1_START, S_W1_ITER, S_W2_START, S_W2_FIRST, S_W2_TOP,
     S_W2_GOT_G, S_W2_GOT_F, S_ZOOM_TOP, S_ZOOM_GOT_F, S_ZOOM_GOT_G, S_MOMENTS, S_ACCEPT,
@@ -325,8 +331,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             // The host selects this form only when K == KREG, KP == 2 * CHP, and every row (and the zero row behind the
             // last one, P.zrow) is within 4 GiB of P.betaT.
             constexpr int CH = KREG / 2, CHP = CH | 1, RPI = WAVE / CHP, PITCH = 2 * CHP;   // 16-byte pieces per row (odd: conflict-free b128 reads), rows per fetch, doubles per staged row
-            constexpr int RWX = (((KREG - 1) * (KREG - 1) * 4) / (CHP * 16)) & ~7;          // rows in one wave's half of the BFGS matrix area, whole octets
-            constexpr int RW = RWX < WAVE ? RWX : WAVE;
+            // Staging rows per wave and phase: 32 -- TWO round trips to the L2 for the wave's 64 register rows (three with the 24
+            // rows that fit a half of the BFGS matrix' area; a round trip is ~3 k cycles under load and nothing overlaps it).  The
+            // two waves' staging areas reach DMA_STAGE_EXTRA doubles beyond that area: the host sizes the dynamic LDS for it.
+            constexpr int RW = 32;
             static_assert(RW >= 8 && RW % RPI == 0 && WAVE % 8 == 0, "staging area");
             constexpr unsigned long long FULL = RPI * CHP >= 64 ? ~0ull : ((1ull << (RPI * CHP)) - 1ull);
             const unsigned K8 = 8u * (unsigned)K;
