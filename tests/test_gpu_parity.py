@@ -148,10 +148,13 @@ def test_post_kernels_ignore_stale_lds(oracle, monkeypatch, K, nd_max):
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} poisoned LDS")
 
 
-def test_k100_two_topics_per_lane(oracle, monkeypatch):
-    """BASELINE config 4's K = 100: the two-topics-per-lane solver and post kernel, per-document
-    Hessian / Cholesky / nu against the oracle, and the device M-step at n = 99 (resident EM iterations
+@pytest.mark.parametrize("big2", ["1", "0"])
+def test_k100_two_topics_per_lane(oracle, monkeypatch, big2):
+    """BASELINE config 4's K = 100: the two-topics-per-lane solver and the post step -- post_big2_kernel (two waves per
+    document; STM_POST_BIG2=1, the default) and the one-wave post_big_kernel it replaced (kept for K > 112 and for A/B runs) --
+    per-document Hessian / Cholesky / nu against the oracle, and the device M-step at n = 99 (resident EM iterations
     against the host-NumPy M-step)."""
+    monkeypatch.setenv("STM_POST_BIG2", big2)
     from strutopy_amd import STM
     from strutopy_amd.corpus import PackedCorpus
     from strutopy_amd.engine import HipEstepEngine
