@@ -741,28 +741,23 @@ static void bss_time(stm_handle *h) {
     // (no pass has completed yet -- the first fused iteration: 0 is reported rather than waiting for it here)
 }
 
-static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentropy, bool em_stage, bool defer_bss = false) {
-    NEED_MODEL(h);
-    if (!h->beta_set) return fail(STM_ERR_INVALID, "stm_estep: beta has not been set");
-    if (!siginv) return fail(STM_ERR_INVALID, "stm_estep: siginv is NULL");
+// What an E-step's launches need that can FAIL on the host -- sizes, device and pinned allocations, function attributes, the
+// occupancy query -- decided BEFORE anything is enqueued: a rank of a multi-GPU fit that returned early between its first launch
+// and the all-reduce would leave its peers waiting in the collective (stm_em_begin plans first and, on failure, still joins them).
+using PostFn = void (*)(stm::PostParams);
+struct EstepPlan {
+    int dbg_stage = 3, post_debug = 0;
+    bool run_post = false, rem_used = false, big = false;
+    PostFn pfn = nullptr;
+    unsigned wg_threads = 64;
+    size_t lds = 0, slab = 0;
+    int64_t grid = 0;
+    int nrep = 0;
+};
+static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
     const int n = h->n, K = h->K;
-    int diag = 1;
-    for (int i = 0; i < n && diag; ++i)
-        for (int j = 0; j < n; ++j)
-            if (i != j && siginv[(size_t)i * n + j] != 0.0) { diag = 0; break; }
-    double sig_bound = 0.0;   // max absolute row sum >= largest eigenvalue (siginv is symmetric)
-    for (int i = 0; i < n; ++i) {
-        double r = 0.0;
-        for (int j = 0; j < n; ++j) r += fabs(siginv[(size_t)i * n + j]);
-        sig_bound = std::max(sig_bound, r);
-    }
-    const size_t KV = (size_t)h->A * K * h->V;
-    const bool wm = K <= stm::PT || h->big2;    // phi through r_dw + the word-major pass (post_big_kernel adds it atomically)
     const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
-
-    // ---- (A) everything that can fail on the host -- sizes, device and pinned allocations, function attributes, the
-    // occupancy query -- BEFORE anything is enqueued: a rank of a multi-GPU fit that returned early between its first
-    // launch and the all-reduce would leave its peers waiting in the collective (stm_em_begin)
+    if (env_int("STM_DEBUG_FAIL_PLAN", 0)) return fail(STM_ERR_HIP, "STM_DEBUG_FAIL_PLAN: simulated allocation failure in the E-step's plan");   // (tests)
     if (em_stage) if (int rc = ensure_pinned(h, &h->stage_sig, &h->stage_sig_cap, sizeof(double) * (size_t)n * n)) return rc;
     // last document's phi is what the reference leaves in self.phi (stm.py:1116)
     h->phi_doc = h->N - 1;
@@ -770,7 +765,6 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         const size_t nd = (size_t)(h->h_indptr[h->N] - h->h_indptr[h->N - 1]);
         if (int rc = ensure(&h->d_phi, &h->phi_len, (size_t)K * nd)) return rc;
     }
-    using PostFn = void (*)(stm::PostParams);
     const bool run_post = (dbg_stage & 2) && h->N > 0;
     const int post_debug = env_int("STM_POST_DEBUG", 0);
     PostFn pfn = nullptr;
@@ -831,6 +825,41 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     }
     // the first stage of the two-stage reductions + the bound's block sums (reduce_copies grows it otherwise)
     if (int rc = ensure(&h->d_red, &h->red_len, (size_t)RED_Y * std::max(slab, (size_t)n * n) + BOUND_BLOCKS)) return rc;
+
+    pl.dbg_stage = dbg_stage; pl.post_debug = post_debug; pl.run_post = run_post; pl.rem_used = rem_used; pl.big = big;
+    pl.pfn = pfn; pl.wg_threads = wg_threads; pl.lds = lds; pl.slab = slab; pl.grid = grid; pl.nrep = nrep;
+    return STM_OK;
+}
+
+static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentropy, bool em_stage, bool defer_bss = false, const EstepPlan *ready = nullptr) {
+    NEED_MODEL(h);
+    if (!h->beta_set) return fail(STM_ERR_INVALID, "stm_estep: beta has not been set");
+    if (!siginv) return fail(STM_ERR_INVALID, "stm_estep: siginv is NULL");
+    const int n = h->n, K = h->K;
+    int diag = 1;
+    for (int i = 0; i < n && diag; ++i)
+        for (int j = 0; j < n; ++j)
+            if (i != j && siginv[(size_t)i * n + j] != 0.0) { diag = 0; break; }
+    double sig_bound = 0.0;   // max absolute row sum >= largest eigenvalue (siginv is symmetric)
+    for (int i = 0; i < n; ++i) {
+        double r = 0.0;
+        for (int j = 0; j < n; ++j) r += fabs(siginv[(size_t)i * n + j]);
+        sig_bound = std::max(sig_bound, r);
+    }
+    const size_t KV = (size_t)h->A * K * h->V;
+    const bool wm = K <= stm::PT || h->big2;    // phi through r_dw + the word-major pass (post_big_kernel adds it atomically)
+    // ---- (A) the plan (estep_plan: every fallible host-side step), unless the caller made it already
+    EstepPlan pl_own;
+    if (!ready) { if (int rc = estep_plan(h, em_stage, pl_own)) return rc; }
+    const EstepPlan &pl = ready ? *ready : pl_own;
+    const int post_debug = pl.post_debug;
+    const bool run_post = pl.run_post, rem_used = pl.rem_used;
+    const PostFn pfn = pl.pfn;
+    const unsigned wg_threads = pl.wg_threads;
+    const size_t lds = pl.lds, slab = pl.slab;
+    const int64_t grid = pl.grid;
+    const int nrep = pl.nrep;
+    const int dbg_stage = pl.dbg_stage;
 
     // ---- (B) the E-step, enqueued on the handle's stream
     if (em_stage) {

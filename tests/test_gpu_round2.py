@@ -360,6 +360,32 @@ def test_config5_full_size_invariants_oracle_sample_and_mstep(oracle):
     m.close()
 
 
+def test_a_rank_that_fails_before_its_first_launch_still_joins_the_collectives(monkeypatch):
+    """stm_em_begin with a communicator: a rank whose host-side planning fails (an allocation, a function attribute) has
+    enqueued nothing yet -- it must still enter the iteration's two all-reduces, with the error slot set, or its peers wait
+    forever.  One-rank RCCL communicator: the failing call returns its own error promptly, the collectives were entered (the
+    next iteration runs on the same communicator and gives the trace of an undisturbed fit)."""
+    from strutopy_amd import STM, dist as sdist
+    from strutopy_amd._lib import StmError
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(600, 1500, 20, n_words=80, seed=21)
+
+    def model():
+        return STM(documents=syn.corpus, dictionary=None, content=False, K=20, X=syn.X, kappa_interactions=False, max_em_iter=3,
+                   sigma_prior=0, convergence_threshold=1e-12, init_type="random", comm=sdist.RcclComm(sdist.TcpGroup(0, 1)))
+    ref = model()
+    ref.expectation_maximization(saving=False)
+    m = model()
+    monkeypatch.setenv("STM_DEBUG_FAIL_PLAN", "1")
+    with pytest.raises(StmError, match="STM_DEBUG_FAIL_PLAN"):
+        m._em_iteration_resident()
+    monkeypatch.delenv("STM_DEBUG_FAIL_PLAN")
+    m.last_bounds = []
+    m.expectation_maximization(saving=False)
+    assert np.allclose(m.last_bounds, ref.last_bounds, rtol=1e-12)
+    ref.close(); m.close()
+
+
 def test_late_em_iteration_40_teacher_forced_against_the_oracle(oracle):
     """Beyond EM iteration ~30 the successful line searches get longer (10 -> 18 evaluations per document): 2000
     documents of the configs[1] shape driven to EM iteration 40 on the device, then that iteration's E-step from the
