@@ -102,10 +102,11 @@ def test_hessian_cholesky_nu_per_document(monkeypatch):
         assert _rel(phi, g["it0_phi_last"]) <= 1e-7, name
 
 
-@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (64, 90), (65, 120), (100, 300), (128, 90)])
+@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (64, 90), (65, 120), (80, 100), (81, 100), (100, 300), (112, 120), (113, 90), (128, 90)])
 def test_shapes_at_the_limits(oracle, K, nd_max):
-    """smallest / largest K of this build (K <= 64: one topic per lane + MFMA post kernel; 64 < K <= 128:
-    two topics per lane) and documents longer than one 64-word tile."""
+    """smallest / largest K of this build (K <= 64: one topic per lane + MFMA post kernel; 64 < K <= 112: two topics per lane
+    in the solver, two waves per document in the post step -- 80 | 81 is where its tile pitch changes, 112 | 113 where the
+    one-wave post_big_kernel takes over; K <= 128) and documents longer than one 64-word tile."""
     from strutopy_amd.engine import estep_host
     rng = np.random.default_rng(K)
     V, N = 900, 70
