@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 // below performs for that lane).
                 bool badl = false;
                 if (DBG && P.prof) { pin(w[0]); pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[1] += c1 - cq; cq = c1; }
+                __builtin_amdgcn_s_setprio(3);   // the pivot chain is the longest serial stretch of the kernel: ahead of the SIMD's other waves
                 double *cbw = cb + lane;
                 const double *cbr = cb + J0;
 #pragma unroll
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                     }
                 }
                 const bool bad = wave_any(badl);
+                __builtin_amdgcn_s_setprio(0);
                 if (DBG && P.prof) { pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[2] += c1 - cq; cq = c1; }
                 if (bad) { ok = false; break; }
                 // pairs (c, c + 1) with the first cell strictly below the diagonal; the second one is then at most the
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             //     x[i] = X[i][c] = -(sum_{l<i} L[i][l] x[l]) / L[i][i]   (x[l] = 0 above the diagonal, x[c] = 1 / L[c][c]);
             //     the rows of L are independent of x, so their loads run ahead of the substitution chain, and every store
             //     comes after every load (one instruction stream, the LDS works in order).
+            __builtin_amdgcn_s_setprio(2);   // a 15-step substitution chain
             {
                 const int c = lane & 15, rb = lane & ~15;
                 const bool has = rb < n;
@@ -651,6 +654,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                     M[st ? base0 + i * rbc + tri_row(i) + c : MDUMP] = x[i];
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             STM_POST_SYNC();
             if (DBG && P.prof) ti[1] = (long long)__builtin_readcyclecounter();
             // (II) X_ij = -X_ii (sum_{j<=k<i} L_ik X_kj) on the matrix cores, block columns left to right, block rows
