@@ -341,6 +341,9 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             idx0 = idx1; c0 = c1; sl0 = sl1; idx1 = idx2; c1 = c2; sl1 = sl2;
         }
         ll += cst * log_pos(Lst);   // the pairs of the last, incomplete batch of tiles (lanes without one: 0 * log(1))
+        // From here to the end of the document the wave runs dependent chains (assembly -> ladder -> inverse -> nu): it goes ahead of
+        // the SIMD's other waves, whose word loops have independent work to fill the gaps (priority 1; 2-3 inside the factorisation)
+        __builtin_amdgcn_s_setprio(1);
         STM_POST_SYNC();
         sth[lane] = isk ? ths : 0.0;   // inside region 0, behind the matrix: the tiles are done
         if (DBG && P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * PROF_SLOTS + 24 + q] = tq[q];
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             if (isn) M[RS(lane) + lane] = diagA;
             STM_POST_SYNC();
             bool ok = true;
+            __builtin_amdgcn_s_setprio(2);   // the factorisation (updates -> panel -> updates ...) is the document's longest dependent stretch
             constexpr int NBP = REM ? NB : NBC;   // REM: the one column beyond the full blocks is a single pivot, below
 #pragma unroll 1
             for (int p = 0; p < NBP && ok; ++p) {
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                     }
                 }
                 const bool bad = wave_any(badl);
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(2);
                 if (DBG && P.prof) { pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[2] += c1 - cq; cq = c1; }
                 if (bad) { ok = false; break; }
                 // pairs (c, c + 1) with the first cell strictly below the diagonal; the second one is then at most the
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 if (lane == R0) Ldiag = ljj;
                 if (wave_any(lane == R0 && !(d > PIVOT_TOL * diagA))) ok = false;
             }
+            __builtin_amdgcn_s_setprio(1);
             return ok;
         };
         auto make_pd = [&]() __attribute__((always_inline)) {  // stm.py:964-984; M holds A (clean)
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         if (P.pd_path) P.pd_path[doc] = path;
         if (fail) {
             atomicMax(P.err_flag, 3 /* STM_ERR_LINALG */);
+            __builtin_amdgcn_s_setprio(0);
             continue;
         }
         if (DBG && P.chol_out) {
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                     M[st ? base0 + i * rbc + tri_row(i) + c : MDUMP] = x[i];
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(1);   // (the rest of the document -- inverse, nu -- stays ahead of the other waves' word loops)
             STM_POST_SYNC();
             if (DBG && P.prof) ti[1] = (long long)__builtin_readcyclecounter();
             // (II) X_ij = -X_ii (sum_{j<=k<i} L_ik X_kj) on the matrix cores, block columns left to right, block rows
@@ -812,6 +818,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (DBG && P.prof && lane == 0 && (P.debug_flags & 32)) for (int q2 = 0; q2 < 4; ++q2) P.prof[doc * PROF_SLOTS + 28 + q2] = tcc[q2];
         if (DBG && P.prof && lane == 0) {
             tp[7] = (long long)__builtin_readcyclecounter();

@@ -399,6 +399,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             const bool fast = xch[X_SLOW] == 0.0 && xch[X_SLOW + 1] == 0.0;
             clean = false;
             bool ok = true;
+            __builtin_amdgcn_s_setprio(2);   // the factorisation is the document's longest dependent stretch (updates -> panel -> updates ...)
 #pragma unroll 1
             for (int p = 0; p < NB && ok; ++p) {
                 const int J0 = 16 * p;
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                     if (DBG && P.prof) { pin(w[0]); pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[1] += c1 - cq; cq = c1; }
                     const bool indiag = (unsigned)(lane - pl0) < 16u;
                     double *cbw = cb + (indiag ? lane - pl0 : 0);
+                    __builtin_amdgcn_s_setprio(3);   // the pivot chain: ahead of the SIMD's other wave (another document's)
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         if (J0 + j < n) {   // uniform
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                             }
                         }
                     }
+                    __builtin_amdgcn_s_setprio(2);
                     if (owner) {
                         const bool bad = wave_any(badl);
                         if (lane == 0) xch[X_BAD] = bad ? 1.0 : 0.0;
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                 if (xch[X_BAD] != 0.0) ok = false;
                 if (DBG && P.prof) { const long long c1 = __builtin_readcyclecounter(); tcc[3] += c1 - cq; }
             }
+            __builtin_amdgcn_s_setprio(0);
             return ok;
         };
         auto make_pd = [&]() __attribute__((always_inline)) {  // stm.py:964-984; M holds A (clean)
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             //     x[i] = X[i][c] = -(sum_{l<i} L[i][l] x[l]) / L[i][i]   (x[l] = 0 above the diagonal, x[c] = 1 / L[c][c]);
             //     the rows of L are independent of x, so their loads run ahead of the substitution chain, and every store
             //     comes after every load (one instruction stream per wave, and the two waves own different blocks).
+            __builtin_amdgcn_s_setprio(2);   // substitution chains, then dependent MFMA chains: ahead of the SIMD's other wave
             {
                 const int c = gl & 15, rb = gl & ~15;
                 const bool has = rb < n;
@@ -728,6 +733,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                     STM_WG_SYNC();
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             if (DBG && P.prof) ti[2] = (long long)__builtin_readcyclecounter();
         }
         if (DBG && P.prof) tp[6] = (long long)__builtin_readcyclecounter();
