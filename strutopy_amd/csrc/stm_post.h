@@ -33,6 +33,15 @@
 #pragma once
 #include "stm_post_common.h"
 
+// Ablation builds (tools/ablate.sh, never shipped): -DSTM_ABLATE=<bits> removes one phase of post_kernel at compile time -- the results are
+// garbage, the PD ladder is forced to accept and no error is raised -- to measure what each phase costs the kernel UNDER CONTENTION
+// (eleven waves per CU: a phase's own cycle count says how long it took, not what removing it would buy).
+//   1 per-word sums   2 b b^T (fragments + matrix cores)   4 lane = topic pass (row sums, remainder row)   8 factorisation
+//   16 inverse   32 nu   64 the tile fetches   128 assembly   256 nothing (the baseline with the ladder forced)
+#ifndef STM_ABLATE
+#define STM_ABLATE 0
+#endif
+
 namespace stm {
 
 // start of row i of the row-packed lower triangle (row i: i + 1 cells, padded to an even count)
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             unsigned long long ex;
             static_assert(TW * PC - 64 * (NQ - 1) == 16, "the last fetch instruction covers 16 chunks");
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int q = 0; q < ((STM_ABLATE & 64) ? 0 : NQ); ++q) {
                 if (q + 1 < NQ)
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(off[q]), "s"(lds0 + 1024u * q), "s"(bT) : "memory");
@@ -244,9 +253,9 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 const double2 *T2 = reinterpret_cast<const double2 *>(T) + w * PC + q * QP;
                 const double2 *E2 = reinterpret_cast<const double2 *>(sex) + q * QP;
                 const double2 *H2 = reinterpret_cast<const double2 *>(eth) + q * QP;
-                double sx = 0.0, sy = 0.0, lx = 0.0, ly = 0.0;
+                double sx = (STM_ABLATE & 1) ? 1.0 : 0.0, sy = 0.0, lx = sx, ly = 0.0;
 #pragma unroll
-                for (int kk = 0; kk < QP; ++kk) {
+                for (int kk = 0; kk < ((STM_ABLATE & 1) ? 0 : QP); ++kk) {
                     const double2 t = T2[kk], e = E2[kk], h = H2[kk];
                     sx = fma(t.x, e.x, sx); sy = fma(t.y, e.y, sy);    // np.sum(a, 0), a = beta * exp(eta~)
                     lx = fma(t.x, h.x, lx); ly = fma(t.y, h.y, ly);    // theta @ a
@@ -277,64 +286,73 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             }
             STM_POST_SYNC();
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[1] += cy - cy0; cy0 = cy; }
-            // -- 2. rowsum(c'), T <- b (lane = topic).  b = a * (sqrt(c) / S) serves both the Hessian (stm.py:1001, which
-            // divides a * sqrt(c) by S: <= 1.5 ulp apart) and phi = b * sqrt(c) (stm.py:1115-1116, this order); rowsum(c') of
-            // stm.py:1002,1011 is the row sum of that same product.  Four words per round, their LDS reads in flight
-            // together.  Words beyond the document carry sqrt(c) / S = 0: b = 0.  (phi itself goes to beta_ss in
-            // stm_betass.h's word-major pass.)
-            if (isk) {
-                double *tc = T + lane;
-                const double2 *wp2 = reinterpret_cast<const double2 *>(wpar);
-#pragma unroll
-                for (int w0 = 0; w0 < TW; w0 += 4) {
-                    double t[4];
-                    double2 wp[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { t[u] = tc[(w0 + u) * PITCH]; wp[u] = wp2[w0 + u]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double b = (t[u] * ex) * wp[u].x;
-                        const double ph = b * wp[u].y;
-                        tc[(w0 + u) * PITCH] = b;
-                        rowc += ph;
-                    }
-                }
-            }
-            STM_POST_SYNC();
-            if (dump_phi && isk)   // the reference keeps the last document's phi (stm.py:1116)
-                for (int w = 0; w < nw; ++w) P.phi_out[(size_t)lane * Nd + t0 + w] = T[w * PITCH + lane] * wpar[2 * w + 1];
-            if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[2] += cy - cy0; cy0 = cy; }
-            // -- 3. b b^T on the matrix cores, upper block triangle
+            // -- 2. rowsum(c') and b b^T.  b = a * (sqrt(c) / S) = (beta * exp(eta~)) * (sqrt(c) / S) serves both the Hessian
+            // (stm.py:1001, which divides a * sqrt(c) by S: <= 1.5 ulp apart) and phi = b * sqrt(c) (stm.py:1115-1116, this
+            // order); rowsum(c') of stm.py:1002,1011 is the row sum of that same product.  b is never written back to the
+            // tile: each reader scales the beta it reads (the same two multiplications, the same bits) -- the matrix cores'
+            // fragments by their topic's exp(eta~) and their word's sqrt(c) / S, the lane = topic pass (row sums in word
+            // order, the remainder row's products) by its own.  Words beyond the document carry sqrt(c) / S = 0: b = 0.
+            // (phi itself goes to beta_ss in stm_betass.h's word-major pass.)
             {
+                const double2 *wp2 = reinterpret_cast<const double2 *>(wpar);
                 const double *tr = T + fq * PITCH + fr;
-                double f[TW / 4][NB];
+                const double *tc = T + (lane < PITCH ? lane : 0);
+                double exf[NB];
 #pragma unroll
-                for (int s = 0; s < TW / 4; ++s)
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) f[s][b] = tr[4 * s * PITCH + 16 * b];
-                // (groups of four words beyond the document's last word are rows of zeros: the last tile skips them)
+                for (int b = 0; b < NB; ++b) exf[b] = sex[16 * b + fr];
+                const double exr = REM ? sex[R0] : 0.0;
+                double h0 = 0.0, h1 = 0.0;
+                // Four words per step: the step's LDS reads first (fragments and the lane = topic pass's cells), then its six
+                // matrix-core instructions, then the pass's arithmetic in their shadow.  Steps beyond the document's last word
+                // are rows of zeros: skipped (they would add +0 everywhere).
 #pragma unroll
                 for (int s = 0; s < TW / 4; ++s) {
                     if (4 * s >= nw) break;   // uniform
-                    int t = 0;
+                    double fl[NB], t[4], tr0[4];
+                    double2 wp[4];
 #pragma unroll
-                    for (int bi = 0; bi < NB; ++bi)
+                    for (int b = 0; b < NB; ++b) fl[b] = tr[4 * s * PITCH + 16 * b];
+                    const double wqs = wpar[2 * (4 * s + fq)];
 #pragma unroll
-                        for (int bj = bi; bj < NB; ++bj, ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s][bi], f[s][bj], acc[t], 0, 0, 0);
-                }
-                if (REM) {
-                    const double *own = T + (lane < PITCH ? lane : 0), *rem = T + R0;
-                    double h0 = 0.0, h1 = 0.0;
-#pragma unroll
-                    for (int w = 0; w < TW; w += 2) {
-                        if (w >= nw) break;   // uniform
-                        h0 = fma(own[w * PITCH], rem[w * PITCH], h0);
-                        h1 = fma(own[(w + 1) * PITCH], rem[(w + 1) * PITCH], h1);
+                    for (int u = 0; u < 4; ++u) {
+                        t[u] = tc[(4 * s + u) * PITCH]; wp[u] = wp2[4 * s + u];
+                        if (REM) tr0[u] = T[(4 * s + u) * PITCH + R0];
                     }
-                    hrem += h0 + h1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(STM_ABLATE & 2)) {
+                        double f[NB];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) f[b] = (fl[b] * exf[b]) * wqs;
+                        int tt = 0;
+#pragma unroll
+                        for (int bi = 0; bi < NB; ++bi)
+#pragma unroll
+                            for (int bj = bi; bj < NB; ++bj, ++tt)
+                                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[bi], f[bj], acc[tt], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // lane = topic (lanes from K on: exp(eta~) = 0 against finite cells)
+                    if (!(STM_ABLATE & 4)) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double b = (t[u] * ex) * wp[u].x;
+                            rowc += b * wp[u].y;
+                            if (REM) {
+                                const double rb = (tr0[u] * exr) * wp[u].x;
+                                if (u & 1) h1 = fma(b, rb, h1); else h0 = fma(b, rb, h0);
+                            }
+                        }
+                    }
+                    // the sums are pinned here, or the step's arithmetic sinks below the later steps' loads (registers)
+                    asm volatile("" : "+v"(rowc), "+v"(h0), "+v"(h1));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (REM) hrem += h0 + h1;
+                if (dump_phi && isk)   // the reference keeps the last document's phi (stm.py:1116)
+                    for (int w = 0; w < nw; ++w)
+                        P.phi_out[(size_t)lane * Nd + t0 + w] = ((T[w * PITCH + lane] * ex) * wpar[2 * w]) * wpar[2 * w + 1];
             }
+            if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[2] += cy - cy0; cy0 = cy; }
             STM_POST_SYNC();
             wait_lds();         // every read of this buffer has returned before the tile after next is fetched into it
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[3] += cy - cy0; }
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         if (DBG && P.prof && lane == 0) for (int q = 0; q < 4; ++q) P.prof[doc * PROF_SLOTS + 24 + q] = tq[q];
         if (DBG && P.prof) tp[2] = (long long)__builtin_readcyclecounter();
         relane();
-        if (wave_any(sbad || (isk && !(rowc >= 0.0)))) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);   // stm.py:1117
+        if (!STM_ABLATE && wave_any(sbad || (isk && !(rowc >= 0.0)))) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);   // stm.py:1117
         const double Ndoc = (double)(long long)wave_sum(csum);
         ll = wave_sum(ll);
 
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         auto cholesky = [&]() __attribute__((always_inline)) -> bool {
             // a pivot never exceeds its diagonal entry (what is subtracted from it are squares, in floating point too): an
             // entry <= 0 (or NaN) fails some pivot test for certain, and the attempt is decided without factorising
-            if (wave_any(isn && !(diagA > 0.0))) return false;
+            if (!STM_ABLATE && wave_any(isn && !(diagA > 0.0))) return false;
             // a pivot never exceeds its diagonal entry and a pivot that passes is above 32 eps of it: with the diagonal in
             // the normal range every accepted pivot is, and the per-pivot range test of sqrt_and_rsqrt can go
             const bool fast = !wave_any(isn && !(diagA > 1e-260 && diagA < 1e270));
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             __builtin_amdgcn_s_setprio(2);   // the factorisation (updates -> panel -> updates ...) is the document's longest dependent stretch
             constexpr int NBP = REM ? NB : NBC;   // REM: the one column beyond the full blocks is a single pivot, below
 #pragma unroll 1
-            for (int p = 0; p < NBP && ok; ++p) {
+            for (int p = 0; p < ((STM_ABLATE & 8) ? 0 : NBP) && ok; ++p) {
                 const int J0 = 16 * p;
                 relane();
                 long long cq = (DBG && P.prof) ? (long long)__builtin_readcyclecounter() : 0;
@@ -489,7 +507,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 const bool bad = wave_any(badl);
                 __builtin_amdgcn_s_setprio(2);
                 if (DBG && P.prof) { pin(w[15]); const long long c1 = __builtin_readcyclecounter(); tcc[2] += c1 - cq; cq = c1; }
-                if (bad) { ok = false; break; }
+                if (bad && !STM_ABLATE) { ok = false; break; }
                 // pairs (c, c + 1) with the first cell strictly below the diagonal; the second one is then at most the
                 // diagonal cell, which is free (it takes X's diagonal later)
 #pragma unroll
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 STM_POST_SYNC();
                 if (DBG && P.prof) { const long long c1 = __builtin_readcyclecounter(); tcc[3] += c1 - cq; }
             }
-            if (REM && ok) {   // the last pivot: A[R0][R0] - sum_k L[R0][k]^2 (row R0 is final: every panel stored its part of it)
+            if (REM && ok && !(STM_ABLATE & 8)) {   // the last pivot: A[R0][R0] - sum_k L[R0][k]^2 (row R0 is final: every panel stored its part of it)
                 relane();
                 const double l = lane < R0 ? M[RS(R0) + lane] : 0.0;
                 const double d = M[RS(R0) + R0] - wave_sum(l * l);
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 if (wave_any(lane == R0 && !(d > PIVOT_TOL * diagA))) ok = false;
             }
             __builtin_amdgcn_s_setprio(1);
+            if (STM_ABLATE) return true;
             return ok;
         };
         auto make_pd = [&]() __attribute__((always_inline)) {  // stm.py:964-984; M holds A (clean)
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         for (int attempt = 0;; ++attempt) {
             relane();
             if (!clean) {
-                assemble();
+                if (!(STM_ABLATE & 128)) assemble();
                 STM_POST_SYNC();
                 clean = true;
                 if (attempt == 0 && isn) {
@@ -610,7 +629,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
         STM_POST_SYNC();
         long long ti[3] = {0, 0, 0};
         if (DBG && P.prof) ti[0] = (long long)__builtin_readcyclecounter();
-        if (!upper) {
+        if (!upper && !(STM_ABLATE & 16)) {
             // X = L^-1 (so that nu = X^T X), blocked by 16 and IN PLACE of L (diagonal in the triangle's free diagonal cells).
             // (I) all diagonal blocks at once, lane = (block, column c), the column in registers:
             //     x[i] = X[i][c] = -(sum_{l<i} L[i][l] x[l]) / L[i][i]   (x[l] = 0 above the diagonal, x[c] = 1 / L[c][c]);
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                         for (int j = 0; j < n; ++j) nu_doc[(size_t)i * n + j] = (j == i) ? v : 0.0;
                 }
             }
-        } else {
+        } else if (!(STM_ABLATE & 32)) {
             if (REM) {   // the last column on the VALU: nu[i][R0] = X[R0][i] X[R0][R0] (row R0 is X's only row with an entry there)
                 const int ic = isn ? lane : nm1;
                 double *cell = sig_acc + (size_t)(NU_TILES - 1) * 4 * WAVE + lane;
