@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
     constexpr int NBC = NB + REM;
     constexpr int PITCH = post_pitch(NB), PC = PITCH / 2;   // tile row pitch in doubles / 16-byte chunks
     constexpr int QP = (PC + 3) / 4;                         // chunks per quarter row in the per-word sums
-    constexpr int NQ = (TW * PC + 63) / 64;                  // LDS-DMA instructions per tile (the last one: 16 lanes)
+    constexpr int RPI = 64 / PC;                             // whole tile rows per LDS-DMA instruction (PC <= 33)
+    constexpr int NQ = (TW + RPI - 1) / RPI;                 // LDS-DMA instructions per tile
     extern __shared__ __attribute__((aligned(16))) double post_lds[];
     int lane = threadIdx.x;
     const int K = P.K, n = P.n, nm1 = n - 1;
@@ -158,42 +159,38 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
             c = P.counts[p0 + (wc < last ? wc : last)];   // masked where it is used: a select here would wait for the load at once
             slot = P.wm_slot[p0 + (wc < last ? wc : last)];   // where this word's r goes (stm_betass.h)
         };
-        // the 16 rows of a tile, betaT -> LDS: chunk c = 64 q + lane (16 bytes) is chunk c mod PC of word c / PC.  Chunks
-        // beyond the topics of a row (K below this instantiation's maximum) repeat its last one: finite, and the sums
-        // meet them with zeros.  All word ids first (one round trip through the crossbar), then the fetches back to back.
+        // the 16 rows of a tile, betaT -> LDS.  One instruction moves RPI WHOLE rows (lane l: 16-byte chunk l mod PC of the instruction's
+        // row l / PC; the lanes beyond RPI rows are masked off), so a lane's (row, chunk) is the same for every instruction and every
+        // tile -- the index arithmetic of a tile is one multiply-add per instruction (rounds 3-4 packed 64 chunks into every
+        // instruction: one instruction fewer per tile at K = 50, eight vector instructions more per instruction).  Chunks beyond the
+        // topics of a row (K below this instantiation's maximum) repeat its last one: finite, and the sums meet them with zeros.
+        // All word ids first (one round trip through the crossbar), then the fetches back to back.
         auto tile_fetch = [&](int idxv, int buf) __attribute__((always_inline)) {
             unsigned off[NQ];
             int id[NQ];
+            const int fr_ = (int)(((unsigned)lane * (65536u / PC + 1u)) >> 16);     // lane / PC (PC <= 33)
+            int fo = lane - (int)__umul24((unsigned)fr_, (unsigned)PC);
+            fo = fo < CP ? fo : CP - 1;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c = 64 * q + lane;
-                int w = (int)(((unsigned)c * (65536u / PC + 1u)) >> 16);      // c / PC for c < 1024 (PC <= 33)
-                int o = c - (int)__umul24((unsigned)w, (unsigned)PC);
-                w = w < TW ? w : TW - 1;
-                o = o < CP ? o : CP - 1;
-                id[q] = __builtin_amdgcn_ds_bpermute(4 * w, idxv);
-                off[q] = 16u * (unsigned)o;
-            }
+            for (int q = 0; q < NQ; ++q) id[q] = __builtin_amdgcn_ds_bpermute(4 * (q * RPI + fr_), idxv);   // (rows >= 16: masked lanes)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) off[q] += __umul24((unsigned)id[q], K8);
+            for (int q = 0; q < NQ; ++q) off[q] = __umul24((unsigned)id[q], K8) + 16u * (unsigned)fo;
             // Hand-written, so that the compiler does not know these loads write the LDS: it would make every LDS read
             // behind them wait for ALL memory operations in flight (it cannot tell the two tile buffers apart) -- the wait
-            // that matters is the counted one at the top of the tile loop.  M0 carries the LDS destination (saved and
-            // restored: the compiler owns it); the last instruction moves the tile's last 16 chunks (exec = lanes 0..15).
+            // that matters is the counted one at the top of the tile loop.  M0 carries the LDS destination and exec the lanes that
+            // hold a chunk (both saved and restored: the compiler owns them).
             const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(post_lds + buf * TILE);
             unsigned keep;
             unsigned long long ex;
-            static_assert(TW * PC - 64 * (NQ - 1) == 16, "the last fetch instruction covers 16 chunks");
 #pragma unroll
             for (int q = 0; q < ((STM_ABLATE & 64) ? 0 : NQ); ++q) {
-                if (q + 1 < NQ)
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(off[q]), "s"(lds0 + 1024u * q), "s"(bT) : "memory");
-                else
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, 0xffff\n\t"
-                                 "global_load_lds_dwordx4 %2, %4\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep), "=&s"(ex) : "v"(off[q]), "s"(lds0 + 1024u * q), "s"(bT) : "memory");
+                constexpr int full = RPI * PC;
+                const int rows = TW - q * RPI < RPI ? TW - q * RPI : RPI;      // (compile-time after unrolling)
+                const unsigned long long mask = rows * PC >= 64 ? ~0ull : ((1ull << (rows * PC)) - 1ull);
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %5\n\t"
+                             "global_load_lds_dwordx4 %2, %4\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep), "=&s"(ex) : "v"(off[q]), "s"(lds0 + 16u * (unsigned)(full * q)), "s"(bT), "s"(mask) : "memory");
             }
         };
 
