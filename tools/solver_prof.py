@@ -30,7 +30,11 @@ for it in range(ITS):
     print(f"it{it}: cycles/doc init {out[:,0].mean():.0f} eval {out[:,1].mean():.0f} sm {out[:,2].mean():.0f} upd {out[:,3].mean():.0f} total {tot.mean():.0f}"
           f" | nfev {d['nfev'].mean():.1f} njev {d['njev'].mean():.1f} nit {d['nit'].mean():.2f} | per eval {out[:,1].mean()/d['nfev'].mean():.0f} sm/eval {out[:,2].mean()/d['nfev'].mean():.0f}"
           f" kernel {m.timings[-1]['kernels']}")
-    if "pd_path" in d: print("   pd_path counts", np.bincount(d["pd_path"], minlength=3))
+    if "pd_path" in d:
+        print("   pd_path counts", np.bincount(d["pd_path"], minlength=3))
+        for pth in np.unique(d["pd_path"]):   # what a rung of the PD ladder costs: the post kernel's phases by path
+            sel = d["pd_path"] == pth
+            print(f"      path {pth}: {sel.sum()} documents, post cycles/doc: assembly {out[sel, 34].mean():.0f}, ladder {out[sel, 35].mean():.0f}, total {out[sel, 32:39].sum(1).mean():.0f}")
     print("   solver set-up cycles/doc (wave 0): gather %.0f, word-count exchange %.0f, lane vectors + g0 %.0f; wave 1 gather incl. slab %.0f" % tuple(out[:, 4:8].mean(0)))
     print("   one evaluation on wave 0, cycles/doc: post + barrier 0 %.0f, max/exp %.0f, barrier 1 %.0f, lse + data term %.0f, barrier 2 %.0f" % tuple(out[:, 40:45].mean(0)))
     names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
