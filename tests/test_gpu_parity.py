@@ -102,11 +102,13 @@ def test_hessian_cholesky_nu_per_document(monkeypatch):
         assert _rel(phi, g["it0_phi_last"]) <= 1e-7, name
 
 
-@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (64, 90), (65, 120), (80, 100), (81, 100), (100, 300), (112, 120), (113, 90), (128, 90)])
+@pytest.mark.parametrize("K,nd_max", [(2, 40), (17, 700), (18, 60), (33, 100), (34, 100), (49, 130), (51, 70), (64, 90), (65, 120), (80, 100), (81, 100), (100, 300),
+                                      (112, 120), (113, 90), (128, 90)])
 def test_shapes_at_the_limits(oracle, K, nd_max):
     """smallest / largest K of this build (K <= 64: one topic per lane + MFMA post kernel; 64 < K <= 112: two topics per lane
     in the solver, two waves per document in the post step -- 80 | 81 is where its tile pitch changes, 112 | 113 where the
-    one-wave post_big_kernel takes over; K <= 128) and documents longer than one 64-word tile."""
+    one-wave post_big_kernel takes over; K <= 128) and documents longer than one 64-word tile.  18 | 33 | 34 | 49 | 51: every block
+    count of post_kernel with and without its remainder row (K = 16 NB + 2), i.e. every rows-per-instruction of the tile fetch."""
     from strutopy_amd.engine import estep_host
     rng = np.random.default_rng(K)
     V, N = 900, 70
@@ -127,7 +129,7 @@ def test_shapes_at_the_limits(oracle, K, nd_max):
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
 
 
-@pytest.mark.parametrize("K,nd_max", [(17, 70), (50, 90), (64, 90), (100, 60), (128, 40)])
+@pytest.mark.parametrize("K,nd_max", [(17, 70), (34, 50), (49, 70), (50, 90), (64, 90), (100, 60), (128, 40)])
 def test_post_kernels_ignore_stale_lds(oracle, monkeypatch, K, nd_max):
     """STM_POST_DEBUG=16 fills the post kernel's LDS with NaN before every document (STM_DEBUG_FLAGS=8: the solver's, per
     workgroup): a masked term that multiplies
