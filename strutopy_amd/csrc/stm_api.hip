@@ -538,8 +538,10 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if ((size_t)K * h->V * sizeof(double) >= ((size_t)1 << 32)) return fail(STM_ERR_INVALID, "stm_set_topics: one level of beta must stay below 4 GiB (32-bit row offsets)");
     h->K = K; h->n = K - 1;
     const size_t N = (size_t)h->N, n = (size_t)h->n, KV = (size_t)h->A * K * h->V;
-    if (int rc = dalloc(&h->d_betaT, KV + 64)) return rc;   // + 64: the kernels read whole 16-byte pieces / KREG <= 64 doubles from a row start, masked beyond K
-    HIP_TRY(hipMemsetAsync(h->d_betaT + KV, 0, sizeof(double) * 64, h->stream));   // ... and what they mask must be finite
+    // + 160: the kernels read whole 16-byte pieces / KREG <= 64 doubles from a row start, masked beyond K, and what they mask must be
+    // finite; the first K <= 128 of them are the ZERO ROW (index A V) that tile fetches of words a document does not have are pointed at
+    if (int rc = dalloc(&h->d_betaT, KV + 160)) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_betaT + KV, 0, sizeof(double) * 160, h->stream));
     // one packed buffer [ scalars(8) | sigma_ss | moments | beta_ss ] so a single all-reduce covers it
     h->extra_cap = round64(moments_len(8, h->n));
     h->pack_len = 8 + n * n + h->extra_cap + KV;

@@ -596,28 +596,77 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         }
 
         const long long t_g2 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-        // ---- DIRECT: one LDS tile of TWS rows, fetched from betaT for every pass over the document.  Lane k loads
-        // components k and k + 64 of each row (two coalesced runs per row, any K), one tile ahead of its use.
-        double pre[DIRECT ? 2 * TWS : 1];
+        // ---- DIRECT: one LDS tile of TWS rows, fetched from betaT for every pass over the document, one tile ahead of its use.
+        // Lane l loads components 2 l and 2 l + 1 of a row: ONE 16-byte load per row and lane (K <= 128: the whole row in one
+        // instruction, scalar base + 32-bit lane offset -- a level of beta stays below 4 GiB, stm_set_topics) and one 16-byte LDS
+        // store (rounds 2-3: components l and l + 64, two masked loads and up to three stores per row -- the sweep spent 2.5 k cycles
+        // per tile issuing them).  The fetch is one straight line: no select behind a load (it would wait for it, row by row) and no
+        // branch per row (the wait-count bookkeeping gives up across them): rows beyond the document repeat its last word and are
+        // zeroed when the tile is STORED, the lanes beyond a row never load (their registers keep the zeros a sweep starts with),
+        // and an odd K's last lane -- which reads 8 bytes into the next row (or the padding behind betaT) -- drops its second
+        // component at the store as well.
+        double2 pre[DIRECT ? TWS : 1];
+        const bool has0 = 2 * lane < K, has1 = 2 * lane + 1 < K;
         auto tile_fetch = [&](int t0) __attribute__((always_inline)) {
             if constexpr (DIRECT) {
-                const int my = (t0 + lane < NdL && lane < TWS) ? sidx[t0 + lane] : 0;
+                if (t0 == 0) {   // a sweep starts (uniform): what the lanes beyond a row store for the whole sweep
 #pragma unroll
-                for (int j = 0; j < TWS; ++j) {
-                    const double *row = bT + (size_t)__builtin_amdgcn_readlane(my, j) * K;
-                    const bool in = t0 + j < NdL;   // uniform
-                    pre[2 * j] = (in && lane < K) ? row[lane] : 0.0;
-                    pre[2 * j + 1] = (in && lane + WAVE < K) ? row[lane + WAVE] : 0.0;
+                    for (int j = 0; j < TWS; ++j) pre[j] = make_double2(0.0, 0.0);
+                }
+                const int wi = t0 + lane < NdL ? t0 + lane : NdL - 1;
+                const int my = (lane < TWS && NdL > 0) ? sidx[wi] : 0;   // (an empty document fetches row 0 and never looks at it)
+                const unsigned l16 = 16u * (unsigned)lane, K8 = 8u * (unsigned)K;
+                const char *base = reinterpret_cast<const char *>(bT);
+                if (has0) {
+#pragma unroll
+                    for (int j = 0; j < TWS; ++j) {
+                        const unsigned o = (unsigned)__builtin_amdgcn_readlane(my, j) * K8 + l16;
+                        double2 v;
+                        __builtin_memcpy(&v, base + o, sizeof(v));      // (8-byte aligned for odd K: global_load_dwordx4 takes it)
+                        pre[j] = v;
+                    }
                 }
             }
         };
-        auto tile_store = [&]() __attribute__((always_inline)) {   // pre -> tile[j][lane], tile[j][lane + 64]; zeros beyond K
+        auto tile_store = [&](int nw) __attribute__((always_inline)) {   // pre -> tile[j][2 lane], tile[j][2 lane + 1]; zeros beyond K and beyond the document
             if constexpr (DIRECT) {
+                const bool odd = K & 1;   // uniform
 #pragma unroll
                 for (int j = 0; j < TWS; ++j) {
-                    slab[(size_t)j * KP + lane] = pre[2 * j];
-                    if (lane + WAVE < KP) slab[(size_t)j * KP + lane + WAVE] = pre[2 * j + 1];
-                    if (lane + 2 * WAVE < KP) slab[(size_t)j * KP + lane + 2 * WAVE] = 0.0;   // K = 127, 128: the row's padding
+                    const bool in = j < nw;   // uniform
+                    pre[j] = make_double2(in ? pre[j].x : 0.0, (in && (!odd || has1)) ? pre[j].y : 0.0);
+                }
+                if (2 * lane < KP) {                                     // (KP is even)
+#pragma unroll
+                    for (int j = 0; j < TWS; ++j) *reinterpret_cast<double2 *>(slab + (size_t)j * KP + 2 * lane) = pre[j];
+                }
+                // K = 127, 128 (KP = 130): the padding of row `lane`, beyond what 64 lanes cover
+                if (KP > 2 * WAVE && lane < TWS) *reinterpret_cast<double2 *>(slab + (size_t)lane * KP + 2 * WAVE) = make_double2(0.0, 0.0);
+            }
+        };
+        // g0 / v of the sweeps below: acc[r] += tile[w][lane + 64 r] * wts[t0 + w] over the tile's words in order, four words' LDS reads in
+        // flight together and no branch on the lane (lanes without a second topic repeat their first one; their sums are never used).
+        // Words beyond the document are rows of zeros in the tile and get the weight 0 (wts is not read beyond the document).
+        auto tile_axpy = [&](const double *wts, int t0, int nw, double (&acc)[VPL]) __attribute__((always_inline)) {
+            if constexpr (DIRECT) {
+                const int c1 = (lane + WAVE < KP) ? lane + WAVE : lane;
+#pragma unroll
+                for (int w0 = 0; w0 < TWS; w0 += 4) {
+                    if (w0 >= nw) break;   // uniform
+                    double wq[4], b0[4], b1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int w = w0 + u;
+                        const double t = wts[t0 + (w < nw ? w : nw - 1)];
+                        wq[u] = w < nw ? t : 0.0;
+                        b0[u] = slab[(size_t)w * KP + lane];
+                        b1[u] = slab[(size_t)w * KP + c1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[0] = fma(b0[u], wq[u], acc[0]);
+                        acc[1] = fma(b1[u], wq[u], acc[1]);
+                    }
                 }
             }
         };
@@ -644,20 +693,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             if (!fuse0) tile_fetch(0);   // (fuse0: g0 comes out of the one sweep that also serves f(x0) and the moment test, below)
             for (int t0 = 0; !fuse0 && t0 < NdL; t0 += TWS) {
                 const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
-                tile_store();
+                tile_store(nw);
                 STM_WAVE_SYNC();
                 if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
-                // g0 += beta_d[:, tile] @ (c / colsum), lane = topic
-#pragma unroll 4
-                for (int w = 0; w < nw; ++w) {
-                    const double wq = wrow[t0 + w];
-#pragma unroll
-                    for (int r = 0; r < VPL; ++r)
-                        if (lane + WAVE * r < KP) {
-                            const double bv = slab[(size_t)w * KP + lane + WAVE * r];
-                            g0a[r] = fma(bv, wq, g0a[r]);
-                        }
-                }
+                tile_axpy(wrow, t0, nw, g0a);   // g0 += beta_d[:, tile] @ (c / colsum), lane = topic
                 STM_WAVE_SYNC();
             }
 #pragma unroll
@@ -813,7 +852,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
                 for (int t0 = 0; t0 < NdL; t0 += TWS) {
                     const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
-                    tile_store();
+                    tile_store(nw);
                     STM_WAVE_SYNC();
                     if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
                     const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);
@@ -1101,22 +1140,25 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 for (int r = 0; r < VPL; ++r) { g0a[r] = 0.0; va[r] = 0.0; }
                 const double2 *se2 = reinterpret_cast<const double2 *>(se);
                 const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
+#ifdef STM_SWEEP_PROF   // a build for tools/solver_prof.py: wait + store / fetch issue / (1) / (2) / (3) into profile slots 40-44
+                long long tsw[5] = {0, 0, 0, 0, 0};
+#define STM_SWEEP_MARK(q, ...) if (P.prof) { __VA_ARGS__; const long long cy = __builtin_readcyclecounter(); tsw[q] += cy - cy0; cy0 = cy; }
+#else
+#define STM_SWEEP_MARK(q, ...)
+#endif
                 tile_fetch(0);
                 for (int t0 = 0; t0 < NdL; t0 += TWS) {
                     const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
-                    tile_store();
+#ifdef STM_SWEEP_PROF
+                    long long cy0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+#endif
+                    tile_store(nw);
                     STM_WAVE_SYNC();
+                    STM_SWEEP_MARK(0, wait_lds())
                     if (t0 + TWS < NdL) tile_fetch(t0 + TWS);
-#pragma unroll 4
-                    for (int w = 0; w < nw; ++w) {   // (1)
-                        const double wq = wrow[t0 + w];
-#pragma unroll
-                        for (int r = 0; r < VPL; ++r)
-                            if (lane + WAVE * r < KP) {
-                                const double bv = slab[(size_t)w * KP + lane + WAVE * r];
-                                g0a[r] = fma(bv, wq, g0a[r]);
-                            }
-                    }
+                    STM_SWEEP_MARK(1, (void)0)
+                    tile_axpy(wrow, t0, nw, g0a);    // (1)
+                    STM_SWEEP_MARK(2, pin(g0a[0]))
                     const double2 *tr = reinterpret_cast<const double2 *>(slab + (size_t)dw * KP);   // (2)
                     double a0 = 0.0, a1 = 0.0;
 #pragma unroll 4
@@ -1135,18 +1177,14 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     STM_WAVE_SYNC();                 // (1)'s reads of wrow are done
                     if (mine) wrow[t0 + dw] = cw / sdot;
                     STM_WAVE_SYNC();
-#pragma unroll 4
-                    for (int w = 0; w < nw; ++w) {   // (3)
-                        const double wq = wrow[t0 + w];
-#pragma unroll
-                        for (int r = 0; r < VPL; ++r)
-                            if (lane + WAVE * r < KP) {
-                                const double bv = slab[(size_t)w * KP + lane + WAVE * r];
-                                va[r] = fma(bv, wq, va[r]);
-                            }
-                    }
+                    STM_SWEEP_MARK(3, wait_lds())
+                    tile_axpy(wrow, t0, nw, va);     // (3)
                     STM_WAVE_SYNC();
+                    STM_SWEEP_MARK(4, pin(va[0]))
                 }
+#ifdef STM_SWEEP_PROF
+                if (P.prof && lane == 0) for (int q = 0; q < 5; ++q) P.prof[doc * PROF_SLOTS + 40 + q] = tsw[q];
+#endif
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) {
                     const int i = lane + WAVE * r;

@@ -36,7 +36,10 @@ for it in range(ITS):
             sel = d["pd_path"] == pth
             print(f"      path {pth}: {sel.sum()} documents, post cycles/doc: assembly {out[sel, 34].mean():.0f}, ladder {out[sel, 35].mean():.0f}, total {out[sel, 32:39].sum(1).mean():.0f}")
     print("   solver set-up cycles/doc (wave 0): gather %.0f, word-count exchange %.0f, lane vectors + g0 %.0f; wave 1 gather incl. slab %.0f" % tuple(out[:, 4:8].mean(0)))
-    print("   one evaluation on wave 0, cycles/doc: post + barrier 0 %.0f, max/exp %.0f, barrier 1 %.0f, lse + data term %.0f, barrier 2 %.0f" % tuple(out[:, 40:45].mean(0)))
+    if KK > 64:   # the K > 64 solver's fused set-up sweep (stm_solver.h, DIRECT; zeros unless the library was built with -DSTM_SWEEP_PROF)
+        print("   K > 64 set-up sweep cycles/doc: wait for the tile + store %.0f, next tile's fetch issue %.0f, g0 %.0f, per-word sums %.0f, v %.0f" % tuple(out[:, 40:45].mean(0)))
+    else:
+        print("   one evaluation on wave 0, cycles/doc: post + barrier 0 %.0f, max/exp %.0f, barrier 1 %.0f, lse + data term %.0f, barrier 2 %.0f" % tuple(out[:, 40:45].mean(0)))
     names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
              "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "MOMENTS", "ACCEPT", "ACCEPT2", "FINISH"]
     pn = ["prologue", "word tiles", "H assembly", "Cholesky ladder", "bound", "inverse", "nu"]
