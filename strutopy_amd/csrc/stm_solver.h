@@ -1420,6 +1420,12 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         STM_UD(ss, old_fval); STM_UD(ss, old_old_fval); STM_UD(ss, gnorm);
         int k = 0, status = 0;
         bool H_ident = true;
+        // K > 64 (the BFGS matrix in HBM): the rank-two update hands the next direction's H g over -- it passes every new H[i][j] through
+        // a register anyway, and S_OUTER_TOP's product would be a third trip over the 78 KB (matvecH's additions, in matvecH's order)
+        double Hg[VPL];
+        bool have_Hg = false;
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) Hg[r] = 0.0;
         // line-search shared
         STM_UD(ss, phi0); STM_UD(ss, old_phi0); STM_UD(ss, derphi0); STM_UD(ss, Lb); STM_UD(ss, Lv); STM_UD(ss, prange);
         STM_UD(ss, sig_lmax);
@@ -1536,6 +1542,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 if (H_ident) {
 #pragma unroll
                     for (int r = 0; r < VPL; ++r) p[r] = -g[r];
+                } else if (NW == 1 && VPL == 2 && have_Hg) {
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r) p[r] = -Hg[r];
+                    have_Hg = false;
                 } else {
                     double t[VPL];
                     matvecH(g, t);
@@ -1928,7 +1938,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 const double cc = rhok * rhok * yHy + rhok;
 #pragma unroll
                 for (int r = 0; r < VPL; ++r)
-                    if (lane + WAVE * r < n) { sv[lane + WAVE * r] = s[r]; sw[lane + WAVE * r] = w[r]; }
+                    if (lane + WAVE * r < n) {
+                        sv[lane + WAVE * r] = s[r]; sw[lane + WAVE * r] = w[r];
+                        if (NW == 1 && VPL == 2) se[lane + WAVE * r] = g[r];   // (free until the next evaluation's head_F rewrites it)
+                    }
                 if (NW == 2) {
                     if (lane == 0) { xch_res[6] = rhok; xch_res[7] = cc; xch_cmd[0] = 8 | (H_ident ? 16 : 0); }
                     __syncthreads();   // (0) wave 1 takes rows [nh, n)
@@ -1940,22 +1953,28 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         const int j0 = lane, j1 = lane + WAVE < n ? lane + WAVE : n - 1;
                         const bool v1 = lane + WAVE < n;
                         const double s0 = s[0], s1 = s[VPL - 1], w0 = w[0], w1 = w[VPL - 1];
+                        double tg0 = 0.0, tg1 = 0.0;   // (H_new g)[j0], [j1]: sum over the rows i in order, as matvecH adds them
                         for (int i = 0; i < n; i += 8) {
-                            double h0[8], h1[8], si[8], wi[8];
+                            double h0[8], h1[8], si[8], wi[8], gi[8];
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const int ic = i + q < n ? i + q : n - 1;
                                 h0[q] = H_ident ? (ic == j0 ? 1.0 : 0.0) : Hs[(size_t)ic * n + j0];
                                 h1[q] = H_ident ? (ic == j1 ? 1.0 : 0.0) : Hs[(size_t)ic * n + j1];
-                                si[q] = sv[ic]; wi[q] = sw[ic];
+                                si[q] = sv[ic]; wi[q] = sw[ic]; gi[q] = se[ic];
                             }
 #pragma unroll
                             for (int q = 0; q < 8; ++q)
                                 if (i + q < n) {   // uniform
-                                    Hs[(size_t)(i + q) * n + j0] = h0[q] - rhok * (si[q] * w0 + wi[q] * s0) + cc * (si[q] * s0);
-                                    if (v1) Hs[(size_t)(i + q) * n + j1] = h1[q] - rhok * (si[q] * w1 + wi[q] * s1) + cc * (si[q] * s1);
+                                    const double n0 = h0[q] - rhok * (si[q] * w0 + wi[q] * s0) + cc * (si[q] * s0);
+                                    const double n1 = h1[q] - rhok * (si[q] * w1 + wi[q] * s1) + cc * (si[q] * s1);
+                                    Hs[(size_t)(i + q) * n + j0] = n0;
+                                    if (v1) Hs[(size_t)(i + q) * n + j1] = n1;
+                                    tg0 += n0 * gi[q]; tg1 += n1 * gi[q];
                                 }
                         }
+                        Hg[0] = tg0; Hg[VPL - 1] = v1 ? tg1 : 0.0;
+                        have_Hg = true;
                     } else
 #pragma unroll
                     for (int r = 0; r < VPL; ++r) {
