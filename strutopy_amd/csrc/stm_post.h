@@ -276,6 +276,13 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 }
                 csum += own ? c : 0.0;
                 if (own) *reinterpret_cast<double2 *>(wpar + 2 * w) = make_double2(wq, sq);
+                // REM: b[w][R0] = (beta exp(eta~)) sqrt(c) / S of the remainder row's topic, once per word here instead of once per
+                // word and LANE in the lane = topic pass below (the same two multiplications).  It goes into the 8-double pads behind
+                // the two tile buffers (words 0..7 / 8..15), which only have to be finite (the sums meet them with zeros).
+                if (REM) {
+                    const double rbw = (T[w * PITCH + R0] * sex[R0]) * wq;
+                    if (own) post_lds[(w >> 3) * TILE + TW * PITCH + (w & 7)] = rbw;
+                }
                 // phi = beta * theta * r (stm_betass.h): r = exp-sum * c / S, in update_z's association (sqrt(c) / S) * sqrt(c).
                 // assert np.all(phi >= 0) (stm.py:1117) fails exactly when a column sum is 0 (0 * inf), infinite or NaN.
                 if (valid && own) P.rw[sl0] = (wq * sq) * sumex;
@@ -297,7 +304,6 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 double exf[NB];
 #pragma unroll
                 for (int b = 0; b < NB; ++b) exf[b] = sex[16 * b + fr];
-                const double exr = REM ? sex[R0] : 0.0;
                 double h0 = 0.0, h1 = 0.0;
                 // Four words per step: the step's LDS reads first (fragments and the lane = topic pass's cells), then its six
                 // matrix-core instructions, then the pass's arithmetic in their shadow.  Steps beyond the document's last word
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
 #pragma unroll
                 for (int s = 0; s < TW / 4; ++s) {
                     if (4 * s >= nw) break;   // uniform
-                    double fl[NB], t[4], tr0[4];
+                    double fl[NB], t[4], rb4[4];
                     double2 wp[4];
 #pragma unroll
                     for (int b = 0; b < NB; ++b) fl[b] = tr[4 * s * PITCH + 16 * b];
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         t[u] = tc[(4 * s + u) * PITCH]; wp[u] = wp2[4 * s + u];
-                        if (REM) tr0[u] = T[(4 * s + u) * PITCH + R0];
+                        if (REM) rb4[u] = post_lds[((4 * s + u) >> 3) * TILE + TW * PITCH + ((4 * s + u) & 7)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(STM_ABLATE & 2)) {
@@ -335,8 +341,7 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                             const double b = (t[u] * ex) * wp[u].x;
                             rowc += b * wp[u].y;
                             if (REM) {
-                                const double rb = (tr0[u] * exr) * wp[u].x;
-                                if (u & 1) h1 = fma(b, rb, h1); else h0 = fma(b, rb, h0);
+                                if (u & 1) h1 = fma(b, rb4[u], h1); else h0 = fma(b, rb4[u], h0);
                             }
                         }
                     }
