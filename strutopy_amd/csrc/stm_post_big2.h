@@ -673,47 +673,60 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                     const int c = c0 + (wv ^ ((c0 >> 1) & 1));
                     const int bc = c * 16 + fr;
                     if (c + 1 < NB) {
+                        // k outermost: step k first closes X_kc (its sum is complete: the rows above are done), then adds L_rk X_kc to the
+                        // sums of ALL rows r > k -- their fragment loads go out together, one LDS round trip per k instead of one per
+                        // (r, k) (21 of them for column 0 at NB = 7, each in front of four dependent matrix-core instructions).  Every
+                        // row's sum still receives its terms in the order k = c, c + 1, ... (four products each): the same bits.
+                        // xcol[r] holds row r's running sum until step r turns it into X_rc.
 #pragma unroll
-                        for (int r = 1; r < NB; ++r) {
-                            if (r > c) {   // uniform
-                                const int ar = r * 16 + fr, arc = ar < n ? ar : nm1;
-                                const double *arow = M + RS(arc);                     // row of L_r* / X_rr for the A operands
-                                v4d sacc = (v4d){0.0, 0.0, 0.0, 0.0};
+                        for (int r = 0; r < NB; ++r) xcol[r] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                                for (int k = 0; k < r; ++k) {
-                                    if (k >= c) {   // uniform
-                                        double av[4];
+                        for (int k = 0; k < NB; ++k) {
+                            if (k >= c) {   // uniform
+                                double bop[4];                                  // B operand of this step: X_kc[4 sk + fq][fr]
+                                if (k == c) {   // X_cc: the lower-triangular diagonal block, from the LDS
 #pragma unroll
-                                        for (int sk = 0; sk < 4; ++sk) av[sk] = arow[k * 16 + 4 * sk + fq];   // L_rk[fr][4 sk + fq] (k < NB - 1: full blocks)
-                                        if (k == c) {   // X_cc: the lower-triangular diagonal block, from the LDS
-                                            double bv[4];
+                                    for (int sk = 0; sk < 4; ++sk) {
+                                        const int kk = k * 16 + 4 * sk + fq;
+                                        const double bv = M[RS(kk) + bc];
+                                        bop[sk] = (bc <= kk) ? bv : 0.0;
+                                    }
+                                } else {        // X_kc = -X_kk (sum): the sum left the matrix cores in the B operand's layout
+                                    const int ar = k * 16 + fr, arc = ar < n ? ar : nm1;
+                                    const double *arow = M + RS(arc);
+                                    double xv[4];
 #pragma unroll
-                                            for (int sk = 0; sk < 4; ++sk) bv[sk] = M[RS(k * 16 + 4 * sk + fq) + bc];
+                                    for (int sk = 0; sk < 4; ++sk) {
+                                        const int ac = k * 16 + 4 * sk + fq;
+                                        xv[sk] = arow[ac < arc ? ac : arc];                 // X_kk[fr][4 sk + fq], at most the diagonal cell
+                                    }
+                                    v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                                            for (int sk = 0; sk < 4; ++sk) {
-                                                const int kk = k * 16 + 4 * sk + fq;
-                                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < n) ? av[sk] : 0.0, (bc <= kk) ? bv[sk] : 0.0, sacc, 0, 0, 0);
-                                            }
-                                        } else {
+                                    for (int sk = 0; sk < 4; ++sk) {
+                                        const int ac = k * 16 + 4 * sk + fq;
+                                        dacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ac <= ar && ar < n) ? xv[sk] : 0.0, xcol[k][sk], dacc, 0, 0, 0);
+                                    }
+                                    xcol[k] = -dacc;
 #pragma unroll
-                                            for (int sk = 0; sk < 4; ++sk)
-                                                sacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < n) ? av[sk] : 0.0, xcol[k][sk], sacc, 0, 0, 0);
-                                        }
+                                    for (int sk = 0; sk < 4; ++sk) bop[sk] = xcol[k][sk];
+                                }
+                                if (k + 1 < NB) {
+                                    double av[NB][4];
+#pragma unroll
+                                    for (int r = k + 1; r < NB; ++r) {
+                                        const int ar = r * 16 + fr, arc = ar < n ? ar : nm1;
+                                        const double *arow = M + RS(arc);                 // row of L_r* for the A operands
+#pragma unroll
+                                        for (int sk = 0; sk < 4; ++sk) av[r][sk] = arow[k * 16 + 4 * sk + fq];   // L_rk[fr][4 sk + fq] (k < NB - 1: full blocks)
+                                    }
+#pragma unroll
+                                    for (int r = k + 1; r < NB; ++r) {
+                                        const int ar = r * 16 + fr;
+#pragma unroll
+                                        for (int sk = 0; sk < 4; ++sk)
+                                            xcol[r] = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < n) ? av[r][sk] : 0.0, bop[sk], xcol[r], 0, 0, 0);
                                     }
                                 }
-                                double xv[4];
-#pragma unroll
-                                for (int sk = 0; sk < 4; ++sk) {
-                                    const int ac = r * 16 + 4 * sk + fq;
-                                    xv[sk] = arow[ac < arc ? ac : arc];                 // X_rr[fr][4 sk + fq], at most the diagonal cell
-                                }
-                                v4d dacc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                                for (int sk = 0; sk < 4; ++sk) {
-                                    const int ac = r * 16 + 4 * sk + fq;
-                                    dacc = __builtin_amdgcn_mfma_f64_16x16x4f64((ac <= ar && ar < n) ? xv[sk] : 0.0, sacc[sk], dacc, 0, 0, 0);
-                                }
-                                xcol[r] = -dacc;
                             }
                         }
                     }
