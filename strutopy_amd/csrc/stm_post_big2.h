@@ -771,47 +771,62 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                 }
             }
         } else {
+            // Row quads outermost, like b b^T: the fragments X[s4 + fq][b 16 + fr], b <= R, of a quad in block row R are read ONCE and serve
+            // every tile (b, bj), b <= bj <= R -- (R + 1)(R + 2) / 2 products per R + 1 loads.  (One block column at a time, as in the
+            // K <= 64 kernel, read the fragments again for every block column: 640 loads and 91 load-then-wait steps per document
+            // at NB = 7 for 252 products.)  Tile (b, bj) is slot bj (bj + 1) / 2 + b of the slab and belongs to wave slot & 1; it still
+            // receives its products in the order s4 = 16 bj, 16 bj + 4, ...: the same bits.
+            auto nu_tiles = [&](auto wc) __attribute__((always_inline)) {
+                constexpr int W = decltype(wc)::value;
+                v4d an[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) an[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int R = 0; R < NB; ++R) {
+                    const int rjR = R * 16 + fr;
 #pragma unroll 1
-            for (int bj = wv; bj < NB; bj += 2) {
-                const int rj = bj * 16 + fr, rjc = rj < n ? rj : nm1;
-                double *slab = sig_acc + (size_t)(bj * (bj + 1) / 2) * 4 * WAVE + lane;
-                v4d an[NB];
+                    for (int s4 = 16 * R; s4 < 16 * R + 16 && s4 < n; s4 += 4) {
+                        const int col = s4 + fq, colc = col < n ? col : nm1;
+                        const double *xr = M + RS(colc);
+                        double g[R + 1];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) an[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-                for (int s4 = bj * 16; s4 < n; s4 += 4) {
-                    const int col = s4 + fq, colc = col < n ? col : nm1;
-                    const double *xr = M + RS(colc);
-                    double f[NB];
+                        for (int bb = 0; bb < R; ++bb) g[bb] = xr[bb * 16 + fr];
+                        g[R] = xr[rjR < n ? rjR : nm1];
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
-                    const double fb = (col < n && rj < n && col >= rj) ? f[NB - 1] : 0.0;   // f[NB - 1] is always block bj's own fragment
+                        for (int bb = 0; bb < R; ++bb) g[bb] = (col < n) ? g[bb] : 0.0;
+                        g[R] = (col < n && rjR < n && col >= rjR) ? g[R] : 0.0;      // X is lower triangular
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        if (b <= bj) {   // uniform
-                            const double fa = (b == bj) ? fb : ((col < n) ? f[b] : 0.0);
-                            an[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, an[b], 0, 0, 0);
-                        }
+                        for (int bj = 0; bj <= R; ++bj)
+#pragma unroll
+                            for (int bb = 0; bb <= bj; ++bb) {
+                                if (((bj * (bj + 1) / 2 + bb) & 1) == W)
+                                    an[(bj * (bj + 1) / 2 + bb) >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[bb], g[bj], an[(bj * (bj + 1) / 2 + bb) >> 1], 0, 0, 0);
+                            }
                     }
                 }
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if (b > bj) continue;   // uniform
+                for (int bj = 0; bj < NB; ++bj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // fire-and-forget: the cell belongs to this wave alone (no contention, program order from one document
-                        // to the next), so the sum is the same every run -- and no old value has to be fetched and held
-                        unsafeAtomicAdd(slab + (b * 4 + r) * WAVE, an[b][r]);
-                        if (DBG && nu_doc) {
-                            const int i = b * 16 + fq + 4 * r, j = rj;
-                            if (i < n && j < n) {
-                                nu_doc[(size_t)i * n + j] = an[b][r];
-                                nu_doc[(size_t)j * n + i] = an[b][r];
+                    for (int bb = 0; bb <= bj; ++bb) {
+                        const int t = bj * (bj + 1) / 2 + bb;
+                        if ((t & 1) != W) continue;
+                        double *slab = sig_acc + (size_t)t * 4 * WAVE + lane;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // fire-and-forget: the cell belongs to this wave alone (no contention, program order from one document
+                            // to the next), so the sum is the same every run -- and no old value has to be fetched and held
+                            unsafeAtomicAdd(slab + r * WAVE, an[t >> 1][r]);
+                            if (DBG && nu_doc) {
+                                const int i = bb * 16 + fq + 4 * r, j = bj * 16 + fr;
+                                if (i < n && j < n) {
+                                    nu_doc[(size_t)i * n + j] = an[t >> 1][r];
+                                    nu_doc[(size_t)j * n + i] = an[t >> 1][r];
+                                }
                             }
                         }
                     }
-                }
-            }
+            };
+            if (wv == 0) nu_tiles(std::integral_constant<int, 0>{}); else nu_tiles(std::integral_constant<int, 1>{});
         }
         if (DBG && P.prof && gl == 0) {
             tp[7] = (long long)__builtin_readcyclecounter();
