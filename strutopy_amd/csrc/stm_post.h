@@ -794,50 +794,59 @@ __global__ __launch_bounds__(64, WPE) void post_kernel(PostParams P) {
                 *cell = oldv + v;
                 if (DBG && nu_doc && isn) { nu_doc[(size_t)lane * n + R0] = v; nu_doc[(size_t)R0 * n + lane] = v; }
             }
-#pragma unroll 1
-            for (int bj = 0; bj < NBV; ++bj) {
-                const int rj = bj * 16 + fr, rjc = rj < n ? rj : nm1;
-                double *slab = sig_acc + (size_t)(bj * (bj + 1) / 2) * 4 * WAVE + lane;
-                v4d an[NBV], old[NBV];
+            // Row quads outermost, like b b^T: the fragments X[s4 + fq][b 16 + fr] of a quad in block row R are read ONCE and serve every
+            // tile (b, bj), b <= bj <= min(R, NBV - 1) (one block column at a time read them again for every block column: 27 load-then-
+            // wait steps per document at K = 50 instead of 13).  Tile (b, bj) sits at slot bj (bj + 1) / 2 + b and still receives its
+            // products in the order s4 = 16 bj, 16 bj + 4, ...: the same bits.
+            constexpr int NVT = NBV * (NBV + 1) / 2;
+            v4d an[NVT], old[NVT];
 #pragma unroll
-                for (int b = 0; b < NBV; ++b) {
-                    an[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    if (b <= bj) {
+            for (int t = 0; t < NVT; ++t) {
+                an[t] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) old[b][r] = slab[(b * 4 + r) * WAVE];
-                    }
-                }
+                for (int r = 0; r < 4; ++r) old[t][r] = sig_acc[(size_t)(t * 4 + r) * WAVE + lane];
+            }
+#pragma unroll
+            for (int R = 0; R < NBC; ++R) {
+                const int RB = R < NBV ? R : NBV - 1;      // last block column this block row feeds (compile-time after unrolling)
+                const int rjR = RB * 16 + fr;
 #pragma unroll 1
-                for (int s4 = bj * 16; s4 < n; s4 += 4) {
+                for (int s4 = 16 * R; s4 < 16 * R + 16 && s4 < n; s4 += 4) {
                     const int col = s4 + fq, colc = col < n ? col : nm1;
                     const double *xr = M + RS(colc);
-                    double f[NBV];
+                    double g[NBV];
 #pragma unroll
-                    for (int b = 0; b < NBV; ++b) f[b] = xr[b < bj ? b * 16 + fr : rjc];   // blocks beyond bj repeat block bj (unused)
-                    const double fb = (col < n && rj < n && col >= rj) ? f[NBV - 1] : 0.0;   // f[NBV - 1] is always block bj's own fragment
+                    for (int bb = 0; bb < NBV; ++bb)
+                        if (bb <= RB) g[bb] = xr[bb * 16 + fr < n ? bb * 16 + fr : nm1];
 #pragma unroll
-                    for (int b = 0; b < NBV; ++b) {
-                        if (b > bj) break;
-                        const double fa = (b == bj) ? fb : ((col < n) ? f[b] : 0.0);
-                        an[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, an[b], 0, 0, 0);
-                    }
+                    for (int bb = 0; bb < NBV; ++bb)
+                        if (bb <= RB) g[bb] = (col < n) ? g[bb] : 0.0;
+                    if (R < NBV) g[RB] = (rjR < n && col >= rjR) ? g[RB] : 0.0;   // the diagonal block row: X is lower triangular
+#pragma unroll
+                    for (int bj = 0; bj < NBV; ++bj)
+#pragma unroll
+                        for (int bb = 0; bb <= bj; ++bb)
+                            if (bj <= RB)
+                                an[bj * (bj + 1) / 2 + bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[bb], g[bj], an[bj * (bj + 1) / 2 + bb], 0, 0, 0);
                 }
+            }
 #pragma unroll
-                for (int b = 0; b < NBV; ++b) {
-                    if (b > bj) break;
+            for (int bj = 0; bj < NBV; ++bj)
+#pragma unroll
+                for (int bb = 0; bb <= bj; ++bb) {
+                    const int t = bj * (bj + 1) / 2 + bb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        slab[(b * 4 + r) * WAVE] = old[b][r] + an[b][r];
+                        sig_acc[(size_t)(t * 4 + r) * WAVE + lane] = old[t][r] + an[t][r];
                         if (DBG && nu_doc) {
-                            const int i = b * 16 + fq + 4 * r, j = rj;
+                            const int i = bb * 16 + fq + 4 * r, j = bj * 16 + fr;
                             if (i < n && j < n) {
-                                nu_doc[(size_t)i * n + j] = an[b][r];
-                                nu_doc[(size_t)j * n + i] = an[b][r];
+                                nu_doc[(size_t)i * n + j] = an[t][r];
+                                nu_doc[(size_t)j * n + i] = an[t][r];
                             }
                         }
                     }
                 }
-            }
         }
         __builtin_amdgcn_s_setprio(0);
         if (DBG && P.prof && lane == 0 && (P.debug_flags & 32)) for (int q2 = 0; q2 < 4; ++q2) P.prof[doc * PROF_SLOTS + 28 + q2] = tcc[q2];
