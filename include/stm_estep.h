@@ -53,7 +53,8 @@ int stm_device_info(stm_handle *h, char *name_out, int name_len, int *cu_count, 
  * 0 <= id < V), counts[nnz] (integers stored as fp64), aspect[N] (level of the
  * content covariate per document, stm.py:527-528; NULL when A == 1).
  * Limits per handle (one GPU's shard), checked before the handle is touched: N < 2^31, nnz < 2^31 (32-bit word-major
- * slots), no empty document.  Besides the CSR arrays the handle keeps the corpus in word-major order for the atomics-free
+ * slots), no empty document, no word id twice in one document (STM_ERR_INVALID: the reference would count such an id's phi
+ * column once in beta_ss and twice everywhere else, stm.py:588; gensim's doc2bow never produces one).  Besides the CSR arrays the handle keeps the corpus in word-major order for the atomics-free
  * beta_ss pass (8 bytes per entry on the device + a host copy of indices[]) -- INTEGRATION.md lists the memory. */
 int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr,
                    const int32_t *indices, const double *counts, const int32_t *aspect, int32_t A);

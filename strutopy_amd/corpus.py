@@ -85,7 +85,7 @@ def pack_bow(documents, V=None):
             c = PackedCorpus(c.indptr, c.indices, c.counts, int(V))
         return _checked(c, V)
     if hasattr(documents, "tocsr") and hasattr(documents, "shape"):      # scipy.sparse, documents x terms
-        m = documents.tocsr()
+        m = documents.tocsr(copy=True)     # tocsr() of a CSR matrix is the caller's object: never canonicalise that in place
         m.sum_duplicates(); m.sort_indices()
         return _checked(PackedCorpus(m.indptr.astype(np.int64), m.indices.astype(np.int32), np.asarray(m.data, dtype=np.float64),
                                      int(m.shape[1] if V is None else max(V, m.shape[1]))), V)
@@ -125,7 +125,26 @@ def pack_bow(documents, V=None):
         V = vmax
     elif vmax > V:
         raise IndexError(f"word id {vmax - 1} is out of range for a dictionary of length {V}")
-    return PackedCorpus(indptr, indices, counts, int(V))
+    return _unique_words(PackedCorpus(indptr, indices, counts, int(V)))
+
+
+def _unique_words(c):
+    """A word id may appear once per document -- what gensim's doc2bow produces and stm_set_corpus requires (the kernels let
+    no two lanes share a word's cells; the reference itself would count a repeated id's phi column once in beta_ss and twice
+    everywhere else, stm.py:588).  Rejected here, with the document named; scipy.sparse input has its duplicates summed."""
+    if len(c.indices) < 2:
+        return c
+    inner = np.ones(len(c.indices) - 1, dtype=bool)
+    inner[np.asarray(c.indptr[1:-1], dtype=np.int64) - 1] = False       # pairs that straddle two documents
+    if not np.all(np.diff(c.indices)[inner] > 0):                       # (rows in ascending order are unique at once)
+        doc = np.repeat(np.arange(c.N, dtype=np.int64), np.diff(c.indptr))
+        key = np.sort(doc * np.int64(max(c.V, 1)) + c.indices)
+        dup = np.flatnonzero(np.diff(key) == 0)
+        if len(dup):
+            d, w = divmod(int(key[dup[0]]), max(c.V, 1))
+            raise ValueError(f"document {d} holds word id {w} more than once: merge the counts first "
+                             "(gensim's doc2bow never produces this)")
+    return c
 
 
 def _checked(c, V):
@@ -140,7 +159,7 @@ def _checked(c, V):
         if len(c.indices) and int(c.indices.max()) >= V:
             raise IndexError(f"word id {int(c.indices.max())} is out of range for a dictionary of length {V}")
         c = PackedCorpus(c.indptr, c.indices, c.counts, int(V))
-    return c
+    return _unique_words(c)
 
 
 def read_mm(path):

@@ -480,6 +480,17 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     }
     for (int64_t q = 0; q < nnz; ++q)
         if (indices[q] < 0 || indices[q] >= V) return fail(STM_ERR_INVALID, "stm_set_corpus: word id out of range");
+    {   // A word id may appear once per document (gensim's doc2bow, what the reference is fed, guarantees it).  The reference
+        // itself would add a repeated id's phi column once (beta_ss[:, idx] += phi with a repeated idx keeps the last write,
+        // stm.py:588) while counting it twice everywhere else; the kernels let no two lanes share a word's cells.  Rejected.
+        std::vector<int32_t> seen((size_t)V, -1);
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t q = indptr[i]; q < indptr[i + 1]; ++q) {
+                if (seen[(size_t)indices[q]] == (int32_t)i)
+                    return fail(STM_ERR_INVALID, "stm_set_corpus: a document holds the same word id twice (merge the counts first)");
+                seen[(size_t)indices[q]] = (int32_t)i;
+            }
+    }
     if (aspect)
         for (int64_t i = 0; i < N; ++i)
             if (aspect[i] < 0 || aspect[i] >= A) return fail(STM_ERR_INVALID, "stm_set_corpus: aspect out of range");

@@ -66,7 +66,9 @@ __host__ __device__ inline Post2Lds post2_lds_map(int K, int PC) {
 __host__ __device__ inline int post2_pc(int K) { return K <= 80 ? 40 : 56; }
 __host__ __device__ inline bool post2_serves(int K) { return K > 64 && K <= 112; }
 
-enum { X_CSUM = 0, X_LL = 2, X_Q = 4, X_DET = 6, X_NEG = 8, X_BAD = 10, X_SLOW = 12 };
+// X_FLAG: four slots -- (attempt parity, wave) -- so that a wave which returns early from attempt a and enters attempt a + 1
+// without a barrier in between (a clean matrix: no assemble) never rewrites a flag its partner has not read yet
+enum { X_CSUM = 0, X_LL = 2, X_Q = 4, X_DET = 6, X_FLAG = 8, X_BAD = 12 };
 
 template <int NB, int PC, bool DBG>
 __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
 
         double diagA = 1.0, Ldiag = 1.0;
         bool clean = false;
+        int chol_calls = 0;
         long long tcc[4] = {0, 0, 0, 0};
         // np.linalg.cholesky, blocked by 16 columns and in place of the packed triangle.  Per panel: (a) the block column
         // minus the products of the finished panels on the matrix cores, block rows dealt out to the two waves; (b) the
@@ -392,11 +395,14 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             // attempt is decided without factorising.  (The diagonal cells of a clean M are not read again: diagA is.)
             const bool neg = wave_any(isn && !(diagA > 0.0));
             const bool slow = wave_any(isn && !(diagA > 1e-260 && diagA < 1e270));   // (see sqrt_and_rsqrt_pivot)
-            if (lane == 0) { xch[X_NEG + wv] = neg ? 1.0 : 0.0; xch[X_SLOW + wv] = slow ? 1.0 : 0.0; }
+            double *flag = xch + X_FLAG + 2 * (chol_calls & 1);
+            ++chol_calls;
+            if (lane == 0) flag[wv] = (neg ? 1.0 : 0.0) + (slow ? 2.0 : 0.0);
             if (isn) M[RS(gl) + gl] = diagA;
             STM_WG_SYNC();
-            if (xch[X_NEG] != 0.0 || xch[X_NEG + 1] != 0.0) return false;
-            const bool fast = xch[X_SLOW] == 0.0 && xch[X_SLOW + 1] == 0.0;
+            const double f0 = flag[0], f1 = flag[1];
+            if (f0 == 1.0 || f0 == 3.0 || f1 == 1.0 || f1 == 3.0) return false;
+            const bool fast = f0 == 0.0 && f1 == 0.0;
             clean = false;
             bool ok = true;
             __builtin_amdgcn_s_setprio(2);   // the factorisation is the document's longest dependent stretch (updates -> panel -> updates ...)

@@ -65,6 +65,7 @@ def shard_bounds(indptr, world):
 # (STM_RDZV_SECRET from the launcher, or a 0600 file in a 0700 directory owned by this user).
 _MAGIC = b"STMRDZV2"
 _MAX_FRAME = 1 << 31
+_SCALAR_TAGS = (b"N", b"T", b"F", b"I", b"D", b"S", b"B")
 
 
 def _enc(obj, out):
@@ -141,7 +142,9 @@ def _dec(buf, pos):
         if n > len(buf) - pos:
             raise ValueError("host group: truncated frame")
         items = []
-        for _ in range(n if tag != b"M" else 2 * n):
+        for q in range(n if tag != b"M" else 2 * n):
+            if tag == b"M" and q % 2 == 0 and buf[pos:pos + 1] not in _SCALAR_TAGS:
+                raise ValueError("host group: a dict key must be a scalar")     # (what _enc sends; a list key would not hash)
             x, pos = _dec(buf, pos)
             items.append(x)
         if tag == b"L":
@@ -158,14 +161,15 @@ def _dec(buf, pos):
         pos += 8 * nd
         cnt = 1
         for d in shape:
-            if d < 0:
+            if d < 0 or d > _MAX_FRAME:
                 raise ValueError("host group: bad array shape")
             cnt *= d
-        if cnt > len(buf) - pos:          # every element takes at least its tag byte
+        # every element takes at least its tag byte; an empty array may not carry huge sibling dimensions into reshape
+        if cnt > len(buf) - pos or (cnt == 0 and any(d > (1 << 20) for d in shape)):
             raise ValueError("host group: truncated frame")
         arr = np.empty(cnt, dtype=object)
         for q in range(cnt):
-            if buf[pos:pos + 1] not in (b"N", b"T", b"F", b"I", b"D", b"S", b"B"):
+            if buf[pos:pos + 1] not in _SCALAR_TAGS:
                 raise ValueError("host group: an object array holds scalars only")
             arr[q], pos = _dec(buf, pos)
         return arr.reshape(shape), pos
@@ -380,6 +384,19 @@ class TcpGroup:
         a = np.array(buf, dtype=np.float64, copy=True)
         return self._reduce(a, np.add if op == "sum" else np.maximum)
 
+    def gather(self, obj, dst=0):
+        """Every rank's object at rank `dst` (a list in rank order), None elsewhere: the shards of theta / eta / mu on their
+        way into save_model's files travel once, to the rank that writes them."""
+        if self.size <= 1:
+            return [obj]
+        if dst != 0:
+            objs = self.allgather(obj)
+            return objs if self.rank == dst else None
+        if self.rank == 0:
+            return [obj] + [_recv_msg(c) for c in self._peers]
+        _send_msg(self._root, obj)
+        return None
+
     def broadcast(self, obj, src=0):
         return self.allgather(obj if self.rank == src else None)[src]
 
@@ -435,6 +452,9 @@ class SingleComm:
     def allgather(self, obj):
         return [obj]
 
+    def gather(self, obj, dst=0):
+        return [obj]
+
     def barrier(self):
         pass
 
@@ -449,6 +469,13 @@ class _GroupComm:
 
     def allgather(self, obj):
         return self.group.allgather(obj)
+
+    def gather(self, obj, dst=0):
+        """List of every rank's object (rank order) on rank `dst`, None on the others."""
+        if hasattr(self.group, "gather"):
+            return self.group.gather(obj, dst)
+        objs = self.group.allgather(obj)
+        return objs if self.rank == dst else None
 
     def barrier(self):
         self.group.barrier()
@@ -499,4 +526,10 @@ class RcclComm(_GroupComm):
         return engine.allreduce_small(buf)
 
     def spectral_reduce(self, engine):
+        # stm_spectral_allreduce is the identity on a handle without a communicator: an engine that was never attached would
+        # silently initialise from its own shard, with a different beta on every rank
+        info = engine.comm_info()
+        if info["nranks"] != self.size:
+            raise RuntimeError(f"RcclComm.spectral_reduce: the engine's communicator has {info['nranks']} ranks, the group "
+                               f"{self.size} (attach() the engine first)")
         engine.spectral_allreduce()     # the Vk x Vk matrix in place on the device (200 MB at maxV = 5000)

@@ -78,16 +78,28 @@ def spectral_init(corpus, K, V, maxV=5000, verbose=True, engine=None, details=No
         wprob, keep = kept_terms(corpus, maxV, comm)
         if verbose:
             print("Create gram matrix...")
-        if hasattr(engine, "spectral_gram_resident"):
-            if not resident:
-                engine.set_corpus(corpus.indptr, corpus.indices, corpus.counts, max(int(V), int(corpus.indices.max()) + 1))
-            engine.spectral_gram_resident(keep, check=not sharded)
+        # a caller's engine keeps the corpus it holds (its aspect / A, longest-first order and word-major index belong to the
+        # caller's model): only an engine created here, or one the caller says already holds `corpus`, runs the resident gram
+        if hasattr(engine, "spectral_gram_resident") and (own or resident):
+            err = ""
+            try:
+                if not resident:
+                    engine.set_corpus(corpus.indptr, corpus.indices, corpus.counts, max(int(V), int(corpus.indices.max()) + 1))
+                engine.spectral_gram_resident(keep, check=not sharded)
+            except Exception as e:
+                if not sharded:
+                    raise
+                err = f"{type(e).__name__}: {e}"
             if sharded:
+                # a rank that failed must not leave its peers waiting in the Vk^2 all-reduce: one status word first
+                errs = [e for e in comm.allgather(err) if e]
+                if errs:
+                    raise RuntimeError("spectral initialisation failed on a rank: " + errs[0])
                 comm.spectral_reduce(engine)
                 engine.spectral_check()
         else:
             if sharded:
-                raise NotImplementedError("this engine has no resident gram: a sharded spectral initialisation needs it")
+                raise NotImplementedError("a sharded spectral initialisation needs the engine's resident gram (resident=True)")
             engine.spectral_gram(corpus.N, len(keep), gram_inputs(corpus, keep))
         if verbose:
             print("Find anchor words...")

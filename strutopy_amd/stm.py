@@ -482,13 +482,44 @@ class STM:
 
     # ------------------------------------------------------------------ persistence (stm.py:1120-1149)
     def save_model(self, output_dir):
+        """stm.py:1120-1149: the same eight files with the same names, shapes and dtypes.
+
+        On a document-sharded fit (comm.size > 1) theta / eta / mu / X are this rank's rows: the shards travel ONCE, one array
+        at a time, over the host group to rank 0 (`comm.gather`; rank order = corpus order, dist.shard_bounds cuts contiguous
+        ranges), and rank 0 alone writes the N x K arrays the reference's callers read back (src/05_train.py:116,
+        src/04_create_synthetic_corpora.py:61-62).  beta, sigma, gamma and the bound trace are replicated.  Every rank
+        returns after rank 0 has written; a failure to write raises on every rank."""
+        comm = self.comm
+        if comm.size <= 1:
+            self._write_model(output_dir, self.theta, self.eta, self.mu, self.X)
+            return
+        rows = {}
+        for name in ("theta", "eta", "mu", "X"):
+            part = getattr(self, name)
+            part = None if part is None else np.asarray(part)
+            parts = comm.gather(part, 0)
+            if comm.rank == 0:
+                rows[name] = None if any(q is None for q in parts) else np.concatenate(parts, axis=0)
+        err = ""
+        if comm.rank == 0:
+            try:
+                if len(rows["theta"]) != self.N_total:
+                    raise RuntimeError(f"save_model: gathered {len(rows['theta'])} rows of theta, the corpus has {self.N_total}")
+                self._write_model(output_dir, rows["theta"], rows["eta"], rows["mu"], rows["X"])
+            except Exception as e:      # the peers are waiting in the collective below: tell them instead of leaving them there
+                err = f"{type(e).__name__}: {e}"
+        err = comm.allgather(err)[0]
+        if err:
+            raise RuntimeError("save_model failed on rank 0: " + err)
+
+    def _write_model(self, output_dir, theta, eta, mu, X):
         os.makedirs(output_dir, exist_ok=True)
         np.save(os.path.join(output_dir, "beta_hat"), self.beta)
-        np.save(os.path.join(output_dir, "theta_hat"), self.theta)
+        np.save(os.path.join(output_dir, "theta_hat"), theta)
         np.save(os.path.join(output_dir, "sigma_hat"), self.sigma)
-        np.save(os.path.join(output_dir, "eta_hat"), self.eta)
-        np.save(os.path.join(output_dir, "mu_hat"), self.mu)
-        np.save(os.path.join(output_dir, "X"), self.X)
+        np.save(os.path.join(output_dir, "eta_hat"), eta)
+        np.save(os.path.join(output_dir, "mu_hat"), mu)
+        np.save(os.path.join(output_dir, "X"), X)
         if self.model == "STM":
             np.save(os.path.join(output_dir, "gamma_hat"), self.gamma)
         with open(os.path.join(output_dir, "lower_bound.pickle"), "wb") as f:

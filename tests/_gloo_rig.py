@@ -22,6 +22,11 @@ class GlooGroup:
         self._dist.all_gather_object(out, obj, group=self._group)
         return out
 
+    def gather(self, obj, dst=0):
+        out = [None] * self.size if self.rank == dst else None
+        self._dist.gather_object(obj, out, dst=dst, group=self._group)
+        return out
+
     def allreduce(self, buf, op="sum"):
         t = self._torch.from_numpy(np.array(buf, dtype=np.float64, copy=True))
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX, group=self._group)

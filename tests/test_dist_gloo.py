@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="binary", init="random"):
+def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="binary", init="random", outdir=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       OMP_NUM_THREADS="2")
     os.environ.pop("STM_RDZV_PORT", None)
@@ -47,9 +47,11 @@ def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="
             kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
             init_type=init, model_type=model_type, comm=comm, engine=OracleEngine(nthreads=2))
     assert m.N_total == full.N
-    m.expectation_maximization(saving=False)
+    m.expectation_maximization(saving=outdir is not None, output_dir=outdir)
     q.put((rank, lo, hi, list(m.last_bounds), m.sigma.copy(), m.beta.copy(), m.mu.copy(), m.eta.copy(),
            getattr(m, "gamma", None)))
+    if outdir is not None:
+        np.save(os.path.join(outdir, f"rank{rank}_theta"), m.theta)     # what this rank held when save_model ran
     comm.barrier()
     if group == "gloo":
         tdist.destroy_process_group()
@@ -74,7 +76,9 @@ def _covariate(g, xkind):
 @pytest.mark.parametrize("case,model_type,group,xkind", [("c1_k10", "STM", "gloo", "binary"), ("toy_ctm", "CTM", "gloo", "binary"),
                                                          ("c1_k10", "STM", "tcp", "binary"), ("c1_k10", "STM", "tcp", "sorted3"),
                                                          ("c1_k10", "STM", "tcp", "pandas_str")])
-def test_two_rank_fit_equals_single_process(case, model_type, group, xkind):
+def test_two_rank_fit_equals_single_process(case, model_type, group, xkind, tmp_path):
+    import pickle
+
     import torch.multiprocessing as mp
     from _oracle_engine import OracleEngine
     from strutopy_amd.corpus import PackedCorpus
@@ -84,7 +88,10 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, model_type, iters, q, group, xkind)) for r in range(2)]
+    out2, out1 = str(tmp_path / "two_ranks"), str(tmp_path / "single")
+    os.makedirs(out2)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, model_type, iters, q, group, xkind, "random", out2))
+             for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
@@ -95,7 +102,27 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind):
     ref = STM(documents=full, dictionary=None, content=False, K=int(g["K"]), X=_covariate(g, xkind),
               kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
               init_type="random", model_type=model_type, engine=OracleEngine())
-    ref.expectation_maximization(saving=False)
+    ref.expectation_maximization(saving=True, output_dir=out1)
+    # save_model on the sharded fit (stm.py:1120-1149, called from stm.py:880): rank 0 alone wrote the reference's files, with
+    # the N x K arrays of the WHOLE corpus -- exactly the two shards' rows in corpus order -- and the single-process fit's
+    # file set / shapes / dtypes
+    shard_files = sorted(f for f in os.listdir(out2) if f.startswith("rank"))
+    assert shard_files == ["rank0_theta.npy", "rank1_theta.npy"]
+    assert sorted(set(os.listdir(out2)) - set(shard_files)) == sorted(os.listdir(out1))
+    assert np.array_equal(np.load(os.path.join(out2, "theta_hat.npy")),
+                          np.concatenate([np.load(os.path.join(out2, f)) for f in shard_files]))
+    assert np.array_equal(np.load(os.path.join(out2, "eta_hat.npy")), np.concatenate([res[0][7], res[1][7]]))
+    assert np.array_equal(np.load(os.path.join(out2, "mu_hat.npy")), np.concatenate([res[0][6], res[1][6]]))
+    for f in sorted(os.listdir(out1)):
+        if f.endswith(".npy"):
+            a, b = (np.load(os.path.join(d, f), allow_pickle=True) for d in (out2, out1))
+            assert a.shape == b.shape and a.dtype == b.dtype, f
+            if f == "X.npy":
+                assert np.array_equal(a, b)         # the covariate rows, in corpus order
+            else:
+                assert np.allclose(a, b, rtol=1e-7, atol=1e-8), f
+    with open(os.path.join(out2, "lower_bound.pickle"), "rb") as fh:
+        assert pickle.load(fh) == res[0][3]
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == full.N
     for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma in res:
         # the ELBO is the all-reduced sum; the second iteration sees the first one's 1e-16 summation-order differences amplified
@@ -260,6 +287,10 @@ def test_host_group_wire_format_round_trips_without_pickle():
         sdist._decode(b"O\x01" + struct_pack_q(1) + b"L" + struct_pack_q(0))   # ... and on the way in
     with pytest.raises(ValueError):
         sdist._decode(b"A\x03\x01|O8" + struct_pack_q(1))          # an object-dtype array header is refused
+    with pytest.raises(ValueError):                                # a dict whose key is a list: refused as malformed, not a TypeError
+        sdist._decode(b"M" + struct_pack_q(1) + b"L" + struct_pack_q(0) + b"N")
+    with pytest.raises(ValueError):                                # an empty object array with a huge sibling dimension
+        sdist._decode(b"O\x02" + struct_pack_q(0) + struct_pack_q(1 << 40))
     assert "pickle" not in open(sdist.__file__).read().replace("no pickle", "").replace("unpickled", "")
 
 

@@ -196,6 +196,21 @@ def test_corpus_as_csr_triple_sparse_matrix_or_matrix_market_path(tmp_path):
         pack_bow((np.array([0, 1, 1]), np.array([2], dtype=np.int32), np.array([1.0])))         # an empty document
     with pytest.raises(IndexError):
         pack_bow((np.array([0, 1]), np.array([12], dtype=np.int32), np.array([1.0])), V=10)     # word id beyond the dictionary
+    # a word id twice in one document: the reference would count its phi column once in beta_ss and twice
+    # everywhere else (stm.py:588), the kernels let no two lanes share a word -- rejected, whatever the order of the row;
+    # the same id in two documents (also across the boundary) is what a corpus is
+    dup = (np.array([0, 2, 5]), np.array([3, 1, 4, 1, 4], dtype=np.int32), np.ones(5))
+    with pytest.raises(ValueError, match="document 1 holds word id 4"):
+        pack_bow(dup, V=10)
+    with pytest.raises(ValueError, match="more than once"):
+        pack_bow([[(3, 1), (1, 2)], [(4, 1), (1, 1), (4, 2)]])
+    ok = pack_bow((np.array([0, 2, 5]), np.array([3, 1, 1, 4, 3], dtype=np.int32), np.ones(5)), V=10)
+    assert ok.N == 2
+    # a scipy matrix has its duplicates summed (what csr_matrix means by them) -- on a COPY: the caller's matrix keeps its entries
+    raw = sp.csr_matrix((np.ones(5), np.array([3, 1, 4, 1, 4]), np.array([0, 2, 5])), shape=(2, 10))
+    summed = pack_bow(raw)
+    assert summed.indices.tolist() == [1, 3, 1, 4] and summed.counts.tolist() == [1.0, 1.0, 1.0, 2.0]
+    assert raw.indices.tolist() == [3, 1, 4, 1, 4] and raw.nnz == 5
 
 
 # ----------------------------------------------------------------------------- STM mirror
