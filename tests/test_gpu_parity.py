@@ -346,9 +346,10 @@ def test_invalid_inputs_raise_like_the_reference():
         e.set_corpus(np.array([0, 2]), np.array([1, 7]), np.array([1.0, 1.0]), 5)
     with pytest.raises(ValueError, match="same word id twice"):      # stm_set_corpus's own check (the C-ABI may be called directly)
         e.set_corpus(np.array([0, 2, 5]), np.array([3, 1, 4, 1, 4]), np.ones(5), 5)
-    e.set_corpus(np.array([0, 2, 5]), np.array([3, 1, 1, 4, 3]), np.ones(5), 5)   # the same id in two documents is a corpus
     with pytest.raises(ValueError):          # call order
         e.set_topics(4)
+    e.set_corpus(np.array([0, 2, 5]), np.array([3, 1, 1, 4, 3]), np.ones(5), 5)   # the same id in two documents is a corpus
+    e.set_topics(4)
     e.close()
 
 
