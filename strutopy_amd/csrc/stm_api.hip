@@ -897,6 +897,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     sp.order = h->d_order; sp.tick = h->d_tick; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
     sp.err_flag = h->d_err;
     sp.debug_flags = env_int("STM_DEBUG_FLAGS", 0);
+    sp.mom_k0 = env_int("STM_MOM_K0", 2); sp.mom_k1 = env_int("STM_MOM_K1", 4);   // later searches that start with a moment pass (stm_solver.h)
     sp.prof = h->d_prof;
 
     stm::PostParams pp{};

@@ -28,6 +28,33 @@
 #ifndef STM_EVAL_GROUP
 #define STM_EVAL_GROUP 8   // topics per scheduling group of the evaluation's register pass
 #endif
+#ifndef STM_LATER_PASS
+#define STM_LATER_PASS 0   // 1: searches mom_k0 <= k <= mom_k1 start with a moment pass of their own (measured in round 5: a wash at C2 --
+#endif                     // the failing third search is already cut after ONE evaluation -- and the extra code costs the rest 2 %)
+#ifndef STM_LSE_LATE
+#define STM_LSE_LATE 1     // (bit 0: plain evaluations, bit 1: the fused first one -- that one spills) two-wave form: wave 0 takes the log-sum-exp's logarithm together with its word's (log_pos2) behind barrier (1)
+#endif
+#ifndef STM_FUSE_SLAB
+#define STM_FUSE_SLAB 7    // bit 0: data_F, bit 1: words_F3, bit 2: moments_words take the register word and the slab word side by side
+#endif
+#ifndef STM_FUSE_PIPE
+#define STM_FUSE_PIPE 4    // pairs of topics per software-pipelined group of the side-by-side evaluation (0: not pipelined)
+#endif
+#ifndef STM_FUSE_PIPE3
+#define STM_FUSE_PIPE3 2   // the same for the first evaluation's three-sum pass (twelve chains, four reads per pair of topics)
+#endif
+#ifndef STM_REG_PIPE
+#define STM_REG_PIPE 4     // wave 0's register-word pass of a plain evaluation, pipelined the same way (pairs of topics per group)
+#endif
+#ifndef STM_REG_PIPE3
+#define STM_REG_PIPE3 3    // ... and of the first evaluation's three-sum pass
+#endif
+#ifndef STM_QUAD_W0
+#define STM_QUAD_W0 1      // two-wave form: the prior's quadratic form on wave 0 (it waits for wave 1's df at barrier (1) otherwise), its wave sum
+#endif                     // together with the log-sum-exp's
+#ifndef STM_FUSE_GROUP
+#define STM_FUSE_GROUP 4   // topics per scheduling group of the side-by-side three-sum passes (twelve chains)
+#endif
 #ifndef STM_MOM_GROUP
 #define STM_MOM_GROUP 8    // ... of the moment pass (three broadcast vectors, six sums)
 #endif
@@ -67,6 +94,8 @@ struct SolverParams {
     int32_t *err_flag;
     int lds_doubles;        // dynamic LDS of this launch, in doubles (debug bit3 poisons it)
     int zrow;               // DMA form: index of the all-zero row behind the last row of betaT (A * V)
+    int mom_k0, mom_k1;     // searches mom_k0 <= k <= mom_k1 (besides the first one, k = 0) start with a moment pass of their own (S_OUTER_TOP);
+                            // an outcome-neutral choice -- the pass only decides earlier what the search would find out (mom_k1 < mom_k0: none)
     int debug_flags;        // bit0: skip the BFGS loop (bring-up aid); bit1: no line-search cuts, bit2: no reuse of DCSRCH's first
                             // evaluation by wolfe2 (every evaluation scipy makes is made: A/B check of the shortcuts); bit4: no moment
                             // pass in front of the first search (the cuts of rounds 1-2 only)
@@ -827,11 +856,116 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             const double cnt = (double)icnt;
             return log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
         };
+        auto lse_tail = [&](double m, int icnt, double ssum) __attribute__((always_inline)) -> double {   // lse_F behind its wave sum
+            if (icnt == 1) return log1p_pos(ssum) + m;
+            const double cnt = (double)icnt;
+            return log1p(ssum != 0.0 ? ssum / cnt : ssum) + log(cnt) + m;
+        };
+        // exp(eta~ - m) @ beta_d[:, word] for the lane's register word: data_F's two chains
+        auto reg_dot = [&]() __attribute__((always_inline)) -> double {
+            const double2 *se2 = reinterpret_cast<const double2 *>(se);
+            double s0 = 0.0, s1 = 0.0;
+#if STM_REG_PIPE
+            constexpr int GI = STM_REG_PIPE, NI = KR / 2, NG = (NI + GI - 1) / GI;   // software-pipelined groups (see data_F)
+            double2 eb[2][GI];
+#pragma unroll
+            for (int i = 0; i < GI; ++i) eb[0][i] = se2[i < NI ? i : 0];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int i = 0; i < GI; ++i) eb[(g + 1) & 1][i] = se2[(g + 1) * GI + i < NI ? (g + 1) * GI + i : NI - 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < GI; ++i) {
+                    const int q = g * GI + i;
+                    if (q < NI) { s0 = fma(eb[g & 1][i].x, breg[2 * q], s0); s1 = fma(eb[g & 1][i].y, breg[2 * q + 1], s1); }
+                }
+                asm volatile("" : "+v"(s0), "+v"(s1));
+            }
+#else
+#pragma unroll
+            for (int k = 0; k < KR; k += 2) {
+                if (k % STM_EVAL_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+                const double2 e = se2[k / 2];
+                s0 = fma(e.x, breg[k], s0);
+                s1 = fma(e.y, breg[k + 1], s1);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            return s0 + s1;
+        };
         // c . (m + log(exp(eta~ - m) @ beta_d)) restricted to this wave's words, per lane.
         // (e_lane: exp(eta~ - m) of topic `lane`, 0 beyond K -- kept for broadcast experiments.)
         auto data_F = [&](double m, double e_lane, const int NdL) __attribute__((always_inline)) -> double {  // NdL shadows: slab words to cover
             double part = 0.0;
             const double2 *se2 = reinterpret_cast<const double2 *>(se);
+            if constexpr (DMA && (STM_FUSE_SLAB & 1)) {
+                // The wave that owns the slab (at most one slab word per lane: documents up to 192 words): the lane's register word and
+                // its slab word TOGETHER -- the same four FMA chains and the same two logarithms as below, one after the other there,
+                // side by side here (they share the broadcast reads of exp(eta~ - m), and each chain fills the other's latencies; this
+                // wave is the one the other waits for at the evaluation's last barrier).  K == KREG == KP in this form.
+                if (NdL > 0 && NdL <= WAVE) {   // uniform
+                    const int ia = lane < NdL ? lane : NdL - 1;
+                    const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                    double s0 = 0.0, s1 = 0.0, a0 = 0.0, a1 = 0.0;
+#if STM_FUSE_PIPE
+                    // software-pipelined: a group's LDS reads are in flight while the group before it is multiplied (left to itself every
+                    // group waits out its own round trip to the LDS -- thirteen of them with four topics per group)
+                    constexpr int GI = STM_FUSE_PIPE, NI = KR / 2, NG = (NI + GI - 1) / GI;
+                    double2 eb[2][GI], rb[2][GI];
+#pragma unroll
+                    for (int i = 0; i < GI; ++i) { eb[0][i] = se2[i < NI ? i : 0]; rb[0][i] = ra[i < NI ? i : 0]; }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (g + 1 < NG) {
+#pragma unroll
+                            for (int i = 0; i < GI; ++i) {
+                                const int q = (g + 1) * GI + i < NI ? (g + 1) * GI + i : NI - 1;
+                                eb[(g + 1) & 1][i] = se2[q]; rb[(g + 1) & 1][i] = ra[q];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < GI; ++i) {
+                            const int q = g * GI + i;
+                            if (q < NI) {
+                                const double2 e = eb[g & 1][i], ba = rb[g & 1][i];
+                                s0 = fma(e.x, breg[2 * q], s0);
+                                s1 = fma(e.y, breg[2 * q + 1], s1);
+                                a0 = fma(e.x, ba.x, a0);
+                                a1 = fma(e.y, ba.y, a1);
+                            }
+                        }
+                        asm volatile("" : "+v"(s0), "+v"(s1), "+v"(a0), "+v"(a1));
+                    }
+#else
+#pragma unroll
+                    for (int k = 0; k < KR; k += 2) {
+                        if (k % STM_FUSE_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+                        const double2 e = se2[k / 2], ba = ra[k / 2];
+                        s0 = fma(e.x, breg[k], s0);
+                        s1 = fma(e.y, breg[k + 1], s1);
+                        a0 = fma(e.x, ba.x, a0);
+                        a1 = fma(e.y, ba.y, a1);
+                        // (the scheduler otherwise runs the register word's chains first and parks the slab rows in scratch)
+                        if (k % STM_FUSE_GROUP == STM_FUSE_GROUP - 2 || k + 2 >= KR) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(a0), "+v"(a1));
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double sums[2] = {s0 + s1, a0 + a1};
+                    double lg[2];
+#ifdef STM_NO_LOG2
+                    lg[0] = log_pos(sums[0]); lg[1] = log_pos(sums[1]);
+#else
+                    log_pos2(sums, lg);
+#endif
+                    part = (wreg < Nd) ? c0 * (m + lg[0]) : 0.0;
+                    part += (lane < NdL) ? crow[ia] * (m + lg[1]) : 0.0;
+                    return part;
+                }
+            }
             if (KREG > 0) {  // register-resident word: beta_d column in registers, two FMA chains
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -974,15 +1108,113 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // Two-wave form: the FIRST evaluation and the moment pass in one sweep over beta_d (p = -df(x0) is known before f's data
         // term is: df needs no beta_d).  The sums of exp(eta~ - m) beta_d are data_F's, chain for chain, so f(x0) has the bits of
         // the plain evaluation; the two extra sums per word ride on the same register / LDS reads.
-        auto words_F3 = [&](double m, const int NdL, double &part, double &d1, double &d2) __attribute__((always_inline)) {
+        // pair / xu / lu: one more logarithm, lu = log_pos(xu), taken together with the register word's (wave 0: the log-sum-exp's)
+        auto words_F3 = [&](double m, const int NdL, double &part, double &d1, double &d2, const bool pair, const double xu, double &lu) __attribute__((always_inline)) {
             part = 0.0; d1 = 0.0; d2 = 0.0;
             if constexpr (NW == 2) {
                 const double2 *se2 = reinterpret_cast<const double2 *>(se);
                 const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
                 const double2 *sw2 = reinterpret_cast<const double2 *>(sw);
+                if constexpr (DMA && (STM_FUSE_SLAB & 2)) {
+                    if (NdL > 0 && NdL <= WAVE) {   // uniform: register word and slab word side by side (see data_F)
+                        const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;
+                        const int ia = lane < NdL ? lane : NdL - 1;
+                        const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+                        double A0 = 0.0, A1 = 0.0, B0 = 0.0, B1 = 0.0, Q0 = 0.0, Q1 = 0.0;
+#if STM_FUSE_PIPE3
+                        // software-pipelined like data_F's side-by-side loop: a group's four reads per pair of topics fly while the group before is multiplied
+                        constexpr int GI = STM_FUSE_PIPE3, NI = KR / 2, NG = (NI + GI - 1) / GI;
+                        double2 eb[2][GI], ub[2][GI], vb[2][GI], rb[2][GI];
+#pragma unroll
+                        for (int i = 0; i < GI; ++i) { const int q = i < NI ? i : 0; eb[0][i] = se2[q]; ub[0][i] = sv2[q]; vb[0][i] = sw2[q]; rb[0][i] = ra[q]; }
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            if (g + 1 < NG) {
+#pragma unroll
+                                for (int i = 0; i < GI; ++i) {
+                                    const int q = (g + 1) * GI + i < NI ? (g + 1) * GI + i : NI - 1;
+                                    eb[(g + 1) & 1][i] = se2[q]; ub[(g + 1) & 1][i] = sv2[q]; vb[(g + 1) & 1][i] = sw2[q]; rb[(g + 1) & 1][i] = ra[q];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < GI; ++i) {
+                                const int q = g * GI + i;
+                                if (q < NI) {
+                                    const double2 e = eb[g & 1][i], u = ub[g & 1][i], v = vb[g & 1][i], ba = rb[g & 1][i];
+                                    a0 = fma(e.x, breg[2 * q], a0); a1 = fma(e.y, breg[2 * q + 1], a1);
+                                    b0 = fma(u.x, breg[2 * q], b0); b1 = fma(u.y, breg[2 * q + 1], b1);
+                                    q0 = fma(v.x, breg[2 * q], q0); q1 = fma(v.y, breg[2 * q + 1], q1);
+                                    A0 = fma(e.x, ba.x, A0); A1 = fma(e.y, ba.y, A1);
+                                    B0 = fma(u.x, ba.x, B0); B1 = fma(u.y, ba.y, B1);
+                                    Q0 = fma(v.x, ba.x, Q0); Q1 = fma(v.y, ba.y, Q1);
+                                }
+                            }
+                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(q0), "+v"(q1), "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1), "+v"(Q0), "+v"(Q1));
+                        }
+#else
+#pragma unroll
+                        for (int k = 0; k < KR; k += 2) {
+                            if (k % STM_FUSE_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+                            const double2 e = se2[k / 2], u = sv2[k / 2], v = sw2[k / 2], ba = ra[k / 2];
+                            a0 = fma(e.x, breg[k], a0); a1 = fma(e.y, breg[k + 1], a1);
+                            b0 = fma(u.x, breg[k], b0); b1 = fma(u.y, breg[k + 1], b1);
+                            q0 = fma(v.x, breg[k], q0); q1 = fma(v.y, breg[k + 1], q1);
+                            A0 = fma(e.x, ba.x, A0); A1 = fma(e.y, ba.y, A1);
+                            B0 = fma(u.x, ba.x, B0); B1 = fma(u.y, ba.y, B1);
+                            Q0 = fma(v.x, ba.x, Q0); Q1 = fma(v.y, ba.y, Q1);
+                            if (k % STM_FUSE_GROUP == STM_FUSE_GROUP - 2 || k + 2 >= KR)   // all twelve chains advance together (see data_F)
+                                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(q0), "+v"(q1), "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1), "+v"(Q0), "+v"(Q1));
+                        }
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                        const double sums[2] = {a0 + a1, A0 + A1};
+                        double lg[2], m1, var, M1, VAR;
+                        log_pos2(sums, lg);
+                        mv(sums[0], b0 + b1, q0 + q1, m1, var);
+                        mv(sums[1], B0 + B1, Q0 + Q1, M1, VAR);
+                        const bool in = wreg < Nd, ins = lane < NdL;
+                        part = in ? cw * (m + lg[0]) : 0.0;
+                        d1 = in ? cw * m1 : 0.0;
+                        d2 = in ? cw * var : 0.0;
+                        part += ins ? crow[ia] * (m + lg[1]) : 0.0;
+                        d1 += ins ? crow[ia] * M1 : 0.0;
+                        d2 += ins ? crow[ia] * VAR : 0.0;
+                        return;
+                    }
+                }
                 {
                     const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;   // (= c0; see moments_words)
                     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+#if STM_REG_PIPE3
+                    constexpr int GI = STM_REG_PIPE3, NI = KR / 2, NG = (NI + GI - 1) / GI;   // software-pipelined groups (see data_F)
+                    double2 eb[2][GI], ub[2][GI], vb[2][GI];
+#pragma unroll
+                    for (int i = 0; i < GI; ++i) { const int q = i < NI ? i : 0; eb[0][i] = se2[q]; ub[0][i] = sv2[q]; vb[0][i] = sw2[q]; }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        if (g + 1 < NG) {
+#pragma unroll
+                            for (int i = 0; i < GI; ++i) {
+                                const int q = (g + 1) * GI + i < NI ? (g + 1) * GI + i : NI - 1;
+                                eb[(g + 1) & 1][i] = se2[q]; ub[(g + 1) & 1][i] = sv2[q]; vb[(g + 1) & 1][i] = sw2[q];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < GI; ++i) {
+                            const int q = g * GI + i;
+                            if (q < NI) {
+                                const double2 e = eb[g & 1][i], u = ub[g & 1][i], v = vb[g & 1][i];
+                                a0 = fma(e.x, breg[2 * q], a0); a1 = fma(e.y, breg[2 * q + 1], a1);
+                                b0 = fma(u.x, breg[2 * q], b0); b1 = fma(u.y, breg[2 * q + 1], b1);
+                                q0 = fma(v.x, breg[2 * q], q0); q1 = fma(v.y, breg[2 * q + 1], q1);
+                            }
+                        }
+                        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(q0), "+v"(q1));
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < KR; k += 2) {
                         if (k % STM_MOM_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
@@ -991,8 +1223,16 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         b0 = fma(u.x, breg[k], b0); b1 = fma(u.y, breg[k + 1], b1);
                         q0 = fma(v.x, breg[k], q0); q1 = fma(v.y, breg[k + 1], q1);
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
-                    const double s0 = a0 + a1, lg = m + log_pos(s0);
+                    const double s0 = a0 + a1;
+                    double lg;
+                    if (pair) {   // (uniform)
+                        const double sums[2] = {s0, xu};
+                        double l2[2];
+                        log_pos2(sums, l2);
+                        lg = m + l2[0]; lu = l2[1];
+                    } else lg = m + log_pos(s0);
                     double m1, var;
                     mv(s0, b0 + b1, q0 + q1, m1, var);
                     const bool in = wreg < Nd;
@@ -1024,10 +1264,42 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         };
         auto moments_words = [&](double &d1, double &d2, const int NdL) __attribute__((always_inline)) {
             d1 = 0.0; d2 = 0.0;
-            if constexpr (MOM && NW == 1) {
+            if constexpr (MOM && (NW == 1 || STM_LATER_PASS)) {
                 const double2 *se2 = reinterpret_cast<const double2 *>(se);
                 const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
                 const double2 *sw2 = reinterpret_cast<const double2 *>(sw);
+                if constexpr (DMA && (STM_FUSE_SLAB & 4)) {
+                    if (NdL > 0 && NdL <= WAVE) {   // uniform: register word and slab word side by side (see data_F)
+                        const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;
+                        const int ia = lane < NdL ? lane : NdL - 1;
+                        const double2 *ra = reinterpret_cast<const double2 *>(slab + (size_t)ia * KP);
+                        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, q0 = 0.0, q1 = 0.0;
+                        double A0 = 0.0, A1 = 0.0, B0 = 0.0, B1 = 0.0, Q0 = 0.0, Q1 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < KR; k += 2) {
+                            if (k % STM_FUSE_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+                            const double2 e = se2[k / 2], u = sv2[k / 2], v = sw2[k / 2], ba = ra[k / 2];
+                            a0 = fma(e.x, breg[k], a0); a1 = fma(e.y, breg[k + 1], a1);
+                            b0 = fma(u.x, breg[k], b0); b1 = fma(u.y, breg[k + 1], b1);
+                            q0 = fma(v.x, breg[k], q0); q1 = fma(v.y, breg[k + 1], q1);
+                            A0 = fma(e.x, ba.x, A0); A1 = fma(e.y, ba.y, A1);
+                            B0 = fma(u.x, ba.x, B0); B1 = fma(u.y, ba.y, B1);
+                            Q0 = fma(v.x, ba.x, Q0); Q1 = fma(v.y, ba.y, Q1);
+                            if (k % STM_FUSE_GROUP == STM_FUSE_GROUP - 2 || k + 2 >= KR)   // all twelve chains advance together (see data_F)
+                                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(q0), "+v"(q1), "+v"(A0), "+v"(A1), "+v"(B0), "+v"(B1), "+v"(Q0), "+v"(Q1));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        double m1, var, M1, VAR;
+                        mv(a0 + a1, b0 + b1, q0 + q1, m1, var);
+                        mv(A0 + A1, B0 + B1, Q0 + Q1, M1, VAR);
+                        const bool in = wreg < Nd, ins = lane < NdL;
+                        d1 = in ? cw * m1 : 0.0;
+                        d2 = in ? cw * var : 0.0;
+                        d1 += ins ? crow[ia] * M1 : 0.0;
+                        d2 += ins ? crow[ia] * VAR : 0.0;
+                        return;
+                    }
+                }
                 if constexpr (KREG > 0) {
                     // the word's count again from memory (L2): a second use of c0 at this site costs 225 spilled registers
                     const double cw = (wreg < Nd) ? P.counts[p0 + wreg] : 0.0;
@@ -1248,16 +1520,26 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         __syncthreads();  // (u) update complete
                         continue;
                     }
+                    if (STM_LATER_PASS && (cmd & 32)) {  // the moment pass of a later search (k >= 1): e, e p~, e p~^2 in se / sv / sw, p in the mailbox
+                        const double pl = (lane < n) ? xch_xt[lane] : 0.0;
+                        double d1, d2;
+                        moments_words(d1, d2, NdL);
+                        d1 = wave_sum(d1); d2 = wave_sum(d2);
+                        const double g0p = wave_sum(g0[0] * pl);
+                        if (lane == 0) { xch_res[3] = g0p; xch_res[5] = d1; xch_res[6] = d2; }
+                        __syncthreads();  // (2) results posted
+                        continue;
+                    }
                     if (cmd & 64) {  // the first evaluation, fused with the moment pass along p = -df(x0) (words_F3)
                         xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
-                        const double q = quad_F();
+                        const double q = STM_QUAD_W0 ? 0.0 : quad_F();
                         eval_DF();
                         if (lane < n) xch_gv[lane] = gv[0];
                         __syncthreads();  // (1) df posted; exp(eta~ - m) in se[], m in xch_res[2]
                         const double pl = -gv[0];   // (0 beyond n)
                         __syncthreads();  // (1b) exp(eta~ - m) p~ and exp(eta~ - m) p~^2 in sv[] / sw[]
-                        double part, d1, d2;
-                        words_F3(uni(xch_res[2]), NdL, part, d1, d2);
+                        double part, d1, d2, lu_unused;
+                        words_F3(uni(xch_res[2]), NdL, part, d1, d2, false, 0.0, lu_unused);
                         part = wave_sum(part); d1 = wave_sum(d1); d2 = wave_sum(d2);
                         const double g0p = wave_sum(g0[0] * pl);
                         if (lane == 0) { xch_res[0] = part; xch_res[1] = q; xch_res[3] = g0p; xch_res[5] = d1; xch_res[6] = d2; }
@@ -1267,7 +1549,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
                     // while wave 0 works on max / exp(eta~ - m): the pieces that do not need them
                     double q = 0.0;
-                    if (cmd & 1) q = quad_F();
+                    if ((cmd & 1) && !STM_QUAD_W0) q = quad_F();
                     if (cmd & 2) {
                         eval_DF();
                         if (lane < n) xch_gv[lane] = gv[0];
@@ -1304,24 +1586,46 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             if (lane == 0) xch_cmd[0] = (do_f ? 1 : 0) | (do_g ? 2 : 0);
             __syncthreads();   // (0) wave 1 starts on df and the quadratic form ...
             lap(40);
-            double lse = 0.0, part = 0.0;
+            double lse = 0.0, part = 0.0, stot = 0.0, q0 = 0.0;
+            constexpr bool LATE = (STM_LSE_LATE & 1) && KREG > 0;
             if (do_f) {        // ... while this wave takes max / exp(eta~ - m) and the log-sum-exp
                 head_F(m, icnt, ssum, e_lane);
                 if (lane == 0) xch_res[2] = m;
-                lse = lse_F(m, icnt, ssum);
+                if (STM_QUAD_W0 && sdiag && LATE) {   // (xt - mu)^T siginv (xt - mu): quad_F's terms and sum, beside the log-sum-exp's sum
+                    const double d = xt[0] - mu[0];
+                    double two[2] = {ssum, (lane < n) ? (d * sd[0]) * d : 0.0};
+                    wave_sum_n(two);
+                    stot = two[0]; q0 = two[1];
+                } else {
+                    if (STM_QUAD_W0) q0 = quad_F();
+                    if (LATE) stot = wave_sum(ssum); else lse = lse_F(m, icnt, ssum);
+                }
             }
             lap(41);
             __syncthreads();   // (1)
             lap(42);
             if (do_f) {
-                part = wave_sum(data_F(m, e_lane, 0));   // words 0..63 (wave 1 owns the slab)
+                if (LATE && icnt == 1) {
+                    // lse_F's log1p_pos(s) = log_pos(u) + (s - (u - 1)) / u, u = 1 + s: its logarithm and the word's, the evaluation's two
+                    // long chains on this wave, run side by side (log_pos2: log_pos's operations, its bits) -- and behind the barrier,
+                    // where the other wave has its slab words to do, instead of in front of it
+                    const double u = 1.0 + stot, cr = stot - (u - 1.0);
+                    const double sums[2] = {reg_dot(), u};
+                    double lg[2];
+                    log_pos2(sums, lg);
+                    part = wave_sum((wreg < Nd) ? c0 * (m + lg[0]) : 0.0);
+                    lse = ((u == INFINITY) ? lg[1] : lg[1] + cr * __builtin_amdgcn_rcp(u)) + m;
+                } else {
+                    if (LATE) lse = lse_tail(m, icnt, stot);
+                    part = wave_sum(data_F(m, e_lane, 0));   // words 0..63 (wave 1 owns the slab)
+                }
             }
             lap(43);
             __syncthreads();   // (2)
             lap(44);
             if (do_f) {
                 const double part_all = part + uni(xch_res[0]);
-                const double q = uni(xch_res[1]);
+                const double q = STM_QUAD_W0 ? q0 : uni(xch_res[1]);
                 f_out = 0.5 * q - (part_all - Ndoc * lse);
             }
             if (do_g) gv[0] = (lane < n) ? xch_gv[lane] : 0.0;
@@ -1336,7 +1640,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             __syncthreads();   // (0) wave 1: quadratic form and df
             head_F(m, icnt, ssum, e_lane);
             if (lane == 0) xch_res[2] = m;
-            const double lse = lse_F(m, icnt, ssum);
+            constexpr bool LATE = (STM_LSE_LATE & 2) != 0;
+            double lse = 0.0, stot = 0.0;
+            if (LATE) stot = wave_sum(ssum); else lse = lse_F(m, icnt, ssum);
+            const double qw0 = STM_QUAD_W0 ? quad_F() : 0.0;
             __syncthreads();   // (1)
             gv[0] = (lane < n) ? xch_gv[lane] : 0.0;
             {
@@ -1345,13 +1652,20 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             }
             __syncthreads();   // (1b)
             double part, d1, d2;
-            words_F3(m, 0, part, d1, d2);   // words 0..63 (wave 1 owns the slab)
+            {   // the log-sum-exp's logarithm beside the word's (see eval_split); ONE instance of the three-sum loop either way
+                const bool pair = LATE && icnt == 1;
+                const double u = 1.0 + stot, cr = stot - (u - 1.0);
+                double lu = 0.0;
+                if (LATE && !pair) lse = lse_tail(m, icnt, stot);
+                words_F3(m, 0, part, d1, d2, pair, u, lu);   // words 0..63 (wave 1 owns the slab)
+                if (pair) lse = ((u == INFINITY) ? lu : lu + cr * __builtin_amdgcn_rcp(u)) + m;
+            }
             part = wave_sum(part); d1 = wave_sum(d1); d2 = wave_sum(d2);
             // p^T siginv p here: wave 1 is still on the slab words (its private vector svb is free from barrier (1) on)
             qx_out = quad_of([&](int r) __attribute__((always_inline)) -> double { return -gv[r]; }, svb);
             __syncthreads();   // (2)
             const double part_all = part + uni(xch_res[0]);
-            const double q = uni(xch_res[1]);
+            const double q = STM_QUAD_W0 ? qw0 : uni(xch_res[1]);
             f_out = 0.5 * q - (part_all - Ndoc * lse);
             D1_out = d1 + uni(xch_res[5]); D2_out = py_max2(0.0, d2 + uni(xch_res[6])); g0p_out = uni(xch_res[3]);
         };
@@ -1482,6 +1796,17 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 mD1 = wave_sum(d1); mD2 = py_max2(0.0, wave_sum(d2)); mg0p = dot(g0, p);   // (mqx: S_OUTER_TOP)
                 want_mom = false;
             }
+            if (STM_LATER_PASS && MOM && NW == 2 && want_mom) {   // two-wave form, a search after the first one: both waves sweep their words (no logarithm, no f)
+                if (lane < n) xch_xt[lane] = p[0];
+                if (lane == 0) xch_cmd[0] = 32;
+                __syncthreads();   // (0)
+                double d1, d2;
+                moments_words(d1, d2, 0);   // words 0..63 (wave 1 owns the slab and the complete g0)
+                d1 = wave_sum(d1); d2 = wave_sum(d2);
+                __syncthreads();   // (2)
+                mD1 = d1 + uni(xch_res[5]); mD2 = py_max2(0.0, d2 + uni(xch_res[6])); mg0p = uni(xch_res[3]);
+                want_mom = false;
+            }
             if (want_eval) {
                 // xk + alpha * pk (separate multiply and add, like numpy)
                 double xn[VPL];
@@ -1607,7 +1932,12 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     // both tests hold -- nowhere on (0, b].  Every quantity is bounded in the safe direction (polynomial bounds of
                     // the exponentials where their differences would cancel) and carries a 1e-9 relative allowance; NaNs fail the comparisons.
                     // D1 and D2 cost one pass over beta_d with three sums per word instead of one (moments_words) and no logarithm.
-                    if (MOM && cuts && mproof && k == 0 && derphi0 < 0.0 && range > 0.0) {
+                    // Searches after the first one (mom_k0 <= k <= mom_k1): the same test with a pass of its own -- from EM iteration 5 on the
+                    // documents that move at all take two steps and then a third search that cannot succeed (the fixed point of the
+                    // reference's df is not a minimiser of f), which scipy -- and rounds 1-4 here -- only find out evaluation by evaluation.
+                    // The argument above does not depend on k: x is the current iterate, p = -H g, b the search's first trial step.
+                    const bool later = STM_LATER_PASS && MOM && !DIRECT && k >= P.mom_k0 && k <= P.mom_k1 && k > 0;
+                    if (MOM && cuts && mproof && (k == 0 || later) && derphi0 < 0.0 && range > 0.0) {
                         mvar0 = var0;
                         want_mom = true;
                         if (DIRECT && have0) {   // the sums came with the set-up sweep
@@ -1623,9 +1953,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                             }
                             mD1 = D1; mD2 = py_max2(0.0, wave_sum(t2)) * (1.0 + 1e-9); mg0p = dot(g0, p);
                             mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);
-                        } else if (NW == 1) {
-                            // one-wave forms: the pass runs at the loop's evaluation site (like an evaluation, nothing of this block
-                            // is live across it); its operands go through the LDS.  (Two-wave form: done with the first evaluation.)
+                        } else if (NW == 1 || k > 0) {
+                            // one-wave forms, and the later searches of the two-wave form: the pass runs at the loop's evaluation site (like
+                            // an evaluation, nothing of this block is live across it); its operands go through the LDS.  (Two-wave form,
+                            // k = 0: done with the first evaluation.)
                             mqx = quad_of([&](int r) __attribute__((always_inline)) -> double { return p[r]; }, sv);   // (before sv is an operand)
 #pragma unroll
                             for (int r = 0; r < VPL; ++r) {
@@ -1642,8 +1973,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 st = S_W1_START;
                 if (MOM && want_mom) {
                     st = S_MOMENTS;
-                    if (NW == 1 && !(DIRECT && have0)) break;      // through the loop top for the pass
-                    want_mom = false;        // two-wave form: straight to the verdict
+                    if ((NW == 1 && !(DIRECT && have0)) || (STM_LATER_PASS && NW == 2 && k > 0)) break;      // through the loop top for the pass
+                    want_mom = false;        // two-wave form, first search: straight to the verdict
                 }
             } [[fallthrough]];
             case S_MOMENTS:

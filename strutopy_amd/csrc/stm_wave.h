@@ -92,6 +92,25 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_bcast<DPP_BCAST31, 0xc>(v, 0.0);
     return lane_bcast(v, 63);
 }
+// N sums at once: wave_sum()'s steps on every value, step by step (each result has wave_sum()'s bits).  One reduction is six
+// dependent move-and-add steps with the DPP's wait states in between; N of them fill each other's gaps instead of queueing up.
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double (&v)[N]) {
+#define STM_WS_STEP(expr)                                                 \
+    {                                                                     \
+        _Pragma("unroll") for (int q = 0; q < N; ++q) { const double t = (expr); v[q] += t; } \
+        _Pragma("unroll") for (int q = 0; q < N; ++q) asm volatile("" : "+v"(v[q]));          \
+    }
+    STM_WS_STEP(dpp_move<DPP_XOR1>(v[q]))
+    STM_WS_STEP(dpp_move<DPP_XOR2>(v[q]))
+    STM_WS_STEP(dpp_move<DPP_HALF_MIRROR>(v[q]))
+    STM_WS_STEP(dpp_move<DPP_MIRROR>(v[q]))
+    STM_WS_STEP((dpp_bcast<DPP_BCAST15, 0xa>(v[q], 0.0)))
+    STM_WS_STEP((dpp_bcast<DPP_BCAST31, 0xc>(v[q], 0.0)))
+#undef STM_WS_STEP
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = lane_bcast(v[q], 63);
+}
 // np.max semantics: NaN propagates
 __device__ __forceinline__ double nanmax(double a, double b) {
     return __builtin_isunordered(a, b) ? __builtin_nan("") : fmax(a, b);
@@ -193,6 +212,56 @@ __device__ __forceinline__ double log_pos(double x) {
     res = (x == INFINITY) ? x : res;
     res = (x < 0.0) ? __builtin_nan("") : res;
     return res;  // NaN in -> NaN out through the arithmetic
+}
+// Two logarithms at once: log_pos()'s operations on both arguments, statement by statement -- each result has log_pos()'s bits, and
+// the two dependent chains (~45 instructions each) fill each other's latencies instead of running one after the other (the solver's
+// waves are latency-bound: a dependent fp64 instruction issues every ~9 cycles, an independent one every 4).
+__device__ __forceinline__ void log_pos2(const double (&x)[2], double (&out)[2]) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    double m[2], f[2], d[2], r[2], s[2], z[2], w[2], t1[2], t2[2], R[2], hfsq[2], dk[2], res[2];
+    int e[2];
+    bool low[2];
+    // (a stage is pinned for both arguments before the next one starts: left alone, the scheduler runs one chain after the other)
+#define STM_L2(stmt) { constexpr int q = 0; stmt; } { constexpr int q = 1; stmt; }
+#define STM_P2(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+    STM_L2(m[q] = __builtin_amdgcn_frexp_mant(x[q]))
+    STM_L2(e[q] = __builtin_amdgcn_frexp_exp(x[q]))
+    STM_L2(low[q] = m[q] < 0.70710678118654752440)
+    STM_L2(m[q] = low[q] ? m[q] + m[q] : m[q])
+    STM_L2(e[q] = low[q] ? e[q] - 1 : e[q])
+    STM_L2(f[q] = m[q] - 1.0)
+    STM_L2(d[q] = 2.0 + f[q])
+    STM_L2(r[q] = __builtin_amdgcn_rcp(d[q]))
+    STM_P2(r)
+    double t[2];
+    STM_L2(t[q] = fma(-d[q], r[q], 1.0)) STM_P2(t)
+    STM_L2(r[q] = fma(r[q], t[q], r[q])) STM_P2(r)
+    STM_L2(t[q] = fma(-d[q], r[q], 1.0)) STM_P2(t)
+    STM_L2(r[q] = fma(r[q], t[q], r[q])) STM_P2(r)
+    STM_L2(s[q] = f[q] * r[q]) STM_P2(s)
+    STM_L2(t[q] = fma(-d[q], s[q], f[q])) STM_P2(t)
+    STM_L2(s[q] = fma(t[q], r[q], s[q])) STM_P2(s)
+    STM_L2(z[q] = s[q] * s[q]) STM_P2(z)
+    STM_L2(w[q] = z[q] * z[q]) STM_P2(w)
+    // the two polynomials of one argument are independent chains as well: four chains advance together
+    double u1[2], u2[2];
+    STM_L2(u1[q] = fma(w[q], Lg6, Lg4)) STM_L2(u2[q] = fma(w[q], Lg7, Lg5)) STM_P2(u1) STM_P2(u2)
+    STM_L2(u1[q] = fma(w[q], u1[q], Lg2)) STM_L2(u2[q] = fma(w[q], u2[q], Lg3)) STM_P2(u1) STM_P2(u2)
+    STM_L2(t1[q] = w[q] * u1[q]) STM_L2(u2[q] = fma(w[q], u2[q], Lg1)) STM_P2(t1) STM_P2(u2)
+    STM_L2(t2[q] = z[q] * u2[q]) STM_P2(t2)
+    STM_L2(R[q] = t2[q] + t1[q])
+    STM_L2(hfsq[q] = 0.5 * f[q] * f[q])
+    STM_L2(dk[q] = (double)e[q])
+    STM_L2(res[q] = dk[q] * ln2_hi - ((hfsq[q] - (s[q] * (hfsq[q] + R[q]) + dk[q] * ln2_lo)) - f[q]))
+    STM_L2(res[q] = (x[q] == 0.0) ? -INFINITY : res[q])
+    STM_L2(res[q] = (x[q] == INFINITY) ? x[q] : res[q])
+    STM_L2(out[q] = (x[q] < 0.0) ? __builtin_nan("") : res[q])
+#undef STM_L2
+#undef STM_P2
 }
 // log1p for x >= 0: log(u) + (x - (u - 1)) / u with u = 1 + x (the rounding error of u is
 // recovered exactly by the second term)
