@@ -144,7 +144,7 @@ struct stm_handle {
     size_t slab_beta_len = 0;
     int chunk = 0, nrep = 256;   // documents per launch, replicated nu accumulators
     // solver launch plan: runs of the longest-first order with equal LDS occupancy
-    struct Group { int64_t first, count; int ld; size_t lds_bytes; bool global; };
+    struct Group { int64_t first, count; int ld; size_t lds_bytes; bool global; int64_t resident = 0; };   // resident: workgroups the chip holds at once (two-wave form: the persistent launch's grid)
     std::vector<Group> groups;
     int kreg = 0;                // register-resident topic count of the solver instantiation (0: none)
     int nw = 1;                  // wavefronts per document in the solver
@@ -264,6 +264,7 @@ static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, b
 static int slab_row(int K) { return ((std::max(K, 2) - 2 + 3) / 4) * 4 + 2; }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr int SOLVER_TICKETS = 63;     // ticket counters of the persistent solver launches of one E-step (behind the error flag in d_err)
 constexpr size_t LDS_STATIC = 4096;   // static LDS of the solver kernel (se, sv, sw, mailbox, scalar state) when the runtime cannot be asked
 
 // Cut the longest-first document order into launches of equal LDS occupancy.
@@ -338,6 +339,13 @@ static int plan_solver(stm_handle *h) {
         if (e != hipSuccess) (void)hipGetLastError();
         if (e != hipSuccess) return fail(STM_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
     }
+    if (h->nw == 2)   // persistent launches: what the chip keeps resident of each group's workgroups (registers and this group's LDS)
+        for (auto &gr : h->groups) {
+            if (gr.global) continue;
+            int per = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void *)solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma), 64 * h->nw, gr.lds_bytes) != hipSuccess) { (void)hipGetLastError(); per = 0; }
+            gr.resident = (int64_t)std::max(per, 0) * std::max(h->cu, 1);
+        }
     h->slab_beta_len = glob_len;
     dfree(h->d_slab_beta);
     if (glob_len) if (int rc = dalloc(&h->d_slab_beta, glob_len)) return rc;
@@ -577,7 +585,7 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = dalloc(&h->d_njev, N)) return rc;
     if (int rc = dalloc(&h->d_pd, N)) return rc;
     if (int rc = dalloc(&h->d_counters, 8)) return rc;
-    if (int rc = dalloc(&h->d_err, 1)) return rc;
+    if (int rc = dalloc(&h->d_err, 1 + SOLVER_TICKETS)) return rc;   // [0] the error flag, [1..] the ticket counters of the persistent solver launches
     h->big2 = stm::post2_serves(K) && env_int("STM_POST_BIG2", 1) != 0;
     if (K <= stm::PT || h->big2) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (post_big_kernel adds phi atomically)
     // one block (one wave) per document.  The solver keeps beta_d on chip (64 words in registers,
@@ -886,7 +894,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     } else {
         HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     }
-    HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t) * (1 + SOLVER_TICKETS), h->stream));
     if (!wm || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));   // (the word-major pass writes every cell)
 
     stm::SolverParams sp{};
@@ -918,6 +926,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
 
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    int n_launch = 0;
+    const bool solver_persist = env_int("STM_SOLVER_PERSIST", 1) != 0;
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
             const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma);
@@ -929,7 +939,16 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
                 step = std::min<int64_t>(step, std::max<int64_t>(1, (int64_t)(h->slab_beta_len / ((size_t)(sp.KP + 2) * (size_t)std::max(gr.ld, 1)))));
             for (int64_t off = 0; off < gr.count; off += step) {
                 sp.first = gr.first + off;
-                const unsigned g = (unsigned)std::min<int64_t>(step, gr.count - off);
+                unsigned g = (unsigned)std::min<int64_t>(step, gr.count - off);
+                sp.count = g;
+                sp.ticket_ctr = nullptr;
+                // two-wave form: persistent workgroups, as many as the chip keeps resident, each taking documents off the launch's
+                // ticket counter (stm_solver.h; a launch beyond the counters the E-step zeroes runs one workgroup per document)
+                if (!gr.global && h->nw == 2 && gr.resident > 0 && n_launch < SOLVER_TICKETS && solver_persist) {
+                    sp.ticket_ctr = h->d_err + 1 + n_launch;
+                    g = (unsigned)std::min<int64_t>(g, gr.resident);
+                }
+                ++n_launch;
                 hipLaunchKernelGGL(fn, dim3(g), dim3(bdim), gr.lds_bytes, h->stream, sp);
                 HIP_TRY(hipGetLastError());
             }

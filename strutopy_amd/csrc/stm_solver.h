@@ -52,6 +52,16 @@
 #ifndef STM_QUAD_W0
 #define STM_QUAD_W0 1      // two-wave form: the prior's quadratic form on wave 0 (it waits for wave 1's df at barrier (1) otherwise), its wave sum
 #endif                     // together with the log-sum-exp's
+#ifndef STM_G0_PIPE
+#define STM_G0_PIPE 1      // DMA set-up: g0's lane = topic accumulation reads the next four words' operands ahead
+#endif
+#ifndef STM_SM_BATCH
+#define STM_SM_BATCH 1     // state machine: independent wave reductions of a state run as one batch (wave_reduce_n: same sums, same bits)
+#endif
+#ifndef STM_DCSTEP_ILP
+#define STM_DCSTEP_ILP 0   // dcstep: the independent divisions of a round at once (div_n).  Bit-identical and -0.5 % in the one-document-per-workgroup
+                           // kernel; in the persistent form its extra live values tip the allocator over (51 instead of 17 spilled VGPRs, +15 %): off
+#endif
 #ifndef STM_FUSE_GROUP
 #define STM_FUSE_GROUP 4   // topics per scheduling group of the side-by-side three-sum passes (twelve chains)
 #endif
@@ -87,7 +97,10 @@ struct SolverParams {
     double *slab_H;         // [grid][n][n]
     int ld;                 // slab capacity in words (held outside registers), per launch
     int KP;                 // slab row length: K rounded up to 4j+2 (16-byte rows, conflict-free ds_read_b128)
-    int64_t first;          // this launch covers order[first .. first + gridDim.x)
+    int64_t first;          // this launch covers order[first .. first + count)
+    int64_t count;          // tickets of this launch (gridDim.x of them start as a workgroup's first document)
+    int32_t *ticket_ctr;    // persistent form (two-wave kernels): the launch's ticket counter, zero at launch -- a workgroup takes documents
+                            // gridDim.x + atomicAdd(ticket_ctr, 1) until none are left (nullptr: one document per workgroup, count == gridDim.x)
     const int32_t *order;   // optional processing order (nullable)
     const int64_t *tick;    // optional [N][2]: ticket -> {indptr[doc], doc | Nd << 32} of that order (nullable: the header is read through order / indptr)
     int32_t *status, *nit, *nfev, *njev;
@@ -128,6 +141,82 @@ __device__ __forceinline__ DcStep dcstep(DcStep S, double fp, double dp, double 
     bool brackt = S.brackt;
     const double sgnd = np_sign(dp) * np_sign(dx);
     double stpf, stpc, stpq, theta, s, gamma, p, q, r;
+#if STM_DCSTEP_ILP
+    // The three cases that interpolate between stx and stp share their first two rounds of divisions, and within a round the
+    // quotients do not depend on each other: div_n takes a round at once (every quotient keeps the bits of its own `/`; the one
+    // a case does not use is computed for nothing -- the chain is latency-bound, its issue slots are free).
+    if (fp > fx || sgnd < 0.0 || fabs(dp) < fabs(dx)) {
+        const double A = fx - fp, B = stp - stx;
+        const double n1[3] = {3.0 * A, A, dp}, d1[3] = {B, B, dp - dx};
+        double q1[3];
+        div_n(n1, d1, q1);                       // 3 (fx - fp) / (stp - stx); (fx - fp) / (stp - stx) [case 1's stpq]; dp / (dp - dx) [cases 2, 3]
+        theta = q1[0] + dx + dp;
+        s = py_max3(fabs(theta), fabs(dx), fabs(dp));
+        const double n2[4] = {theta, dx, dp, dx}, d2[4] = {s, s, s, q1[1] + dx};
+        double q2[4];
+        div_n(n2, d2, q2);                       // theta / s, dx / s, dp / s; dx / ((fx - fp) / (stp - stx) + dx) [case 1's stpq]
+        const double rad = q2[0] * q2[0] - q2[1] * q2[2];
+        if (fp > fx) {
+            gamma = s * sqrt(rad);
+            if (stp < stx) gamma *= -1;
+            p = (gamma - dx) + theta;
+            q = ((gamma - dx) + gamma) + dp;
+            r = p / q;
+            stpc = stx + r * (stp - stx);
+            stpq = stx + (q2[3] * 0.5) * (stp - stx);     // (x / 2.0 == x * 0.5 exactly)
+            if (fabs(stpc - stx) <= fabs(stpq - stx)) stpf = stpc;
+            else stpf = stpc + (stpq - stpc) * 0.5;
+            brackt = true;
+        } else if (sgnd < 0.0) {
+            gamma = s * sqrt(rad);
+            if (stp > stx) gamma *= -1;
+            p = (gamma - dp) + theta;
+            q = ((gamma - dp) + gamma) + dx;
+            r = p / q;
+            stpc = stp + r * (stx - stp);
+            stpq = stp + q1[2] * (stx - stp);
+            if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+            else stpf = stpq;
+            brackt = true;
+        } else {
+            gamma = s * sqrt(py_max2(0.0, rad));
+            if (stp > stx) gamma = -gamma;
+            p = (gamma - dp) + theta;
+            q = (gamma + (dx - dp)) + gamma;
+            r = p / q;
+            if (r < 0 && gamma != 0) stpc = stp + r * (stx - stp);
+            else if (stp > stx) stpc = stpmax;
+            else stpc = stpmin;
+            stpq = stp + q1[2] * (stx - stp);
+            if (brackt) {
+                if (fabs(stpc - stp) < fabs(stpq - stp)) stpf = stpc;
+                else stpf = stpq;
+                if (stp > stx) stpf = py_min2(stp + 0.66 * (sty - stp), stpf);
+                else stpf = py_max2(stp + 0.66 * (sty - stp), stpf);
+            } else {
+                if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+                else stpf = stpq;
+                stpf = np_clip(stpf, stpmin, stpmax);
+            }
+        }
+    } else {
+        if (brackt) {
+            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+            s = py_max3(fabs(theta), fabs(dy), fabs(dp));
+            const double n2[3] = {theta, dy, dp}, d2[3] = {s, s, s};
+            double q2[3];
+            div_n(n2, d2, q2);
+            gamma = s * sqrt(q2[0] * q2[0] - q2[1] * q2[2]);
+            if (stp > sty) gamma = -gamma;
+            p = (gamma - dp) + theta;
+            q = ((gamma - dp) + gamma) + dy;
+            r = p / q;
+            stpc = stp + r * (sty - stp);
+            stpf = stpc;
+        } else if (stp > stx) stpf = stpmax;
+        else stpf = stpmin;
+    }
+#else
     if (fp > fx) {
         theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
         s = py_max3(fabs(theta), fabs(dx), fabs(dp));
@@ -190,6 +279,7 @@ __device__ __forceinline__ DcStep dcstep(DcStep S, double fp, double dp, double 
         } else if (stp > stx) stpf = stpmax;
         else stpf = stpmin;
     }
+#endif
     // update the interval which contains a minimizer
     const bool hi = fp > fx, neg = sgnd < 0;
     DcStep R;
@@ -258,7 +348,7 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
 // first update), read back as ds_read_b128 by the lane that owns the word -- and while the rows are there, g0 is summed with
 // lane = topic (two LDS reads, a multiply and an add per word) instead of 50 cross-lane reductions.
 template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1, int DIRECT = 0, bool DMA = false>
-__global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P) {
+__global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P_arg) {
     constexpr int KMAX = 64 * VPL;
     constexpr int VREG = (KREG > 0) ? WAVE * NW : 0;  // words held in registers
     constexpr int KR = (KREG > 0) ? KREG : 2;
@@ -280,32 +370,69 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     __shared__ double ss[64];                       // the scalar state of the line searches (struct ud; wave 0's, Ndoc both waves')
     enum : int { U_old_fval, U_old_old_fval, U_gnorm, U_phi0, U_old_phi0, U_derphi0, U_Lb, U_Lv, U_prange, U_stx, U_fx, U_gx, U_sty, U_fy, U_gy, U_stmin, U_stmax, U_width, U_width1, U_finit, U_ginit, U_gtest, U_w1_a1, U_w1_f1, U_alpha0, U_alpha1, U_phi_a0, U_phi_a1, U_derphi_a0, U_a_lo, U_a_hi, U_phi_lo, U_phi_hi, U_derphi_lo, U_phi_rec, U_a_rec, U_a_j, U_acc_alpha, U_acc_f, U_alpha, U_fval, U_dval, U_cache_f, U_Ndoc, U_sig_lmax, U_mvar0, U_mD1, U_mD2, U_mg0p, U_mqx, U_COUNT };
     static_assert(U_COUNT <= 64, "scalar state");                      // [0] request bits (1 f, 2 g, 4 exit, 8 BFGS update (16: from the identity)), [1..2] bad-beta flags
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = NW == 2 ? uni((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to the compiler as such (scalar branches)
-    if (threadIdx.x < 64) ss[threadIdx.x] = 0.0;   // (read only after the first workgroup barrier)
-    const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
-    double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
-    // DIRECT: dyn_lds = tile[TWS][KP] | crow[ld] | wrow[ld] | sidx[ld] (int32)
-    double *crow = slab + (size_t)KP * (DIRECT ? TWS : ld);  // counts of the slab words
-    // the HBM slab is topic-major (slab[k][word]: a wave's read of one topic for 64 words is one coalesced run), the LDS
-    // slab word-major (slab[word][KP]: a lane streams its own row with ds_read_b128)
-    auto SI = [&](int vv, int k) __attribute__((always_inline)) -> size_t { return GLOBAL_SLAB ? (size_t)k * ld + vv : (size_t)vv * KP + k; };
-    double *wrow = crow + ld;               // counts / colsum(beta_d)
-    int32_t *sidx = reinterpret_cast<int32_t *>(wrow + ld);   // DIRECT: word ids of the document
-    // BFGS inverse-Hessian estimate (n x n): in LDS behind the slab for the two-wave form (its slab is
-    // small), in a private global slab otherwise
-    double *Hs = (NW == 2) ? dyn_lds + (size_t)(KP + 2) * ld : P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
-    const double *S = P.siginv;
-    const bool sdiag = P.siginv_diag != 0;
 
-    // one block (= one wavefront) per document; no work-queue loop: a single-wave workgroup has
-    // no hardware barrier, so cross-lane hand-offs through LDS must not straddle a loop back edge
-    {
-        const int64_t ticket = P.first + blockIdx.x;
-        if (ticket >= P.N) return;
+    // One workgroup per document for the one-wave forms (no work-queue loop: a single-wave workgroup has no hardware barrier, so
+    // cross-lane hand-offs through LDS must not straddle a loop back edge).  The two-wave form is PERSISTENT (round 5): measured
+    // with tools/slot_gaps.py, the chip held 900 of its 1024 document slots busy -- between the end of a workgroup and the first
+    // instruction of the next one in its place lie ~11 k cycles (4.7 us: wave termination, LDS / register release, dispatch and
+    // state initialisation of a two-wave, 256-VGPR, 40 KB-LDS workgroup), 12 % of a document.  A workgroup now takes the next
+    // document off a ticket counter itself: its first ticket is its block index, the following ones gridDim.x + atomicAdd(counter);
+    // the add is issued by wave 1 at the START of a document (its return overlaps the index loads) and parked in the LDS, so the
+    // hand-over at the end of a document is one workgroup barrier.  Tickets are handed out in order, i.e. longest documents first,
+    // whoever is free next -- what the hardware dispatcher did.
+    // The document loop must not look like one to the optimiser's hoisting passes: what does not change from document to document
+    // (lane-derived addresses, flags and pointers of the parameter block) would otherwise be computed in front of the loop and
+    // kept live through every document -- 190 spilled VGPRs and 220 spilled SGPRs in a kernel that sits at 256 registers.  So
+    // the thread index and the address of the parameter block (the kernel-argument segment) are re-read behind an opaque move at
+    // every document, and everything derived from them is a document's own.
+#ifndef STM_SOLVER_PERSIST_FORM
+#define STM_SOLVER_PERSIST_FORM 1
+#endif
+    constexpr bool PERSIST = NW == 2 && STM_SOLVER_PERSIST_FORM;
+    const bool persist = PERSIST && P_arg.ticket_ctr != nullptr;
+    // (two slots, alternating: wave 1 may be a document ahead of wave 0's read of the ticket -- never two, there are barriers in between)
+    __shared__ int tk_slot[2];
+    int tk_par = 0;
+    auto next_doc = [&]() __attribute__((always_inline)) -> int {
+        __syncthreads();      // both waves are done with this document's LDS; the next ticket has long been parked in it
+        const int t = uni(tk_slot[tk_par]);
+        tk_par ^= 1;
+        return t;
+    };
+    for (int tk = blockIdx.x;; tk = next_doc()) {
+        if ((int64_t)tk >= P_arg.count) return;   // (uniform over the workgroup)
+        // (the parameter block is the kernel's one argument: offset 0 of the kernel-argument segment)
+        using ParamT = std::conditional_t<PERSIST, const __attribute__((address_space(4))) SolverParams, const SolverParams>;
+        ParamT *Pk;
+        unsigned tid = threadIdx.x;
+        if constexpr (PERSIST) {
+            Pk = (ParamT *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(Pk), "+v"(tid));
+        } else Pk = &P_arg;
+        ParamT &P = *Pk;
+        const int lane = tid & (WAVE - 1);
+        const int wv = NW == 2 ? uni((int)(tid >> 6)) : 0;   // wave-uniform, and known to the compiler as such (scalar branches)
+        const int K = P.K, n = P.n, ld = P.ld, KP = P.KP;
+        double *slab = GLOBAL_SLAB ? P.slab_beta + (size_t)blockIdx.x * (size_t)(KP + 2) * ld : dyn_lds;
+        // DIRECT: dyn_lds = tile[TWS][KP] | crow[ld] | wrow[ld] | sidx[ld] (int32)
+        double *crow = slab + (size_t)KP * (DIRECT ? TWS : ld);  // counts of the slab words
+        // the HBM slab is topic-major (slab[k][word]: a wave's read of one topic for 64 words is one coalesced run), the LDS
+        // slab word-major (slab[word][KP]: a lane streams its own row with ds_read_b128)
+        auto SI = [&](int vv, int k) __attribute__((always_inline)) -> size_t { return GLOBAL_SLAB ? (size_t)k * ld + vv : (size_t)vv * KP + k; };
+        double *wrow = crow + ld;               // counts / colsum(beta_d)
+        int32_t *sidx = reinterpret_cast<int32_t *>(wrow + ld);   // DIRECT: word ids of the document
+        // BFGS inverse-Hessian estimate (n x n): in LDS behind the slab for the two-wave form (its slab is
+        // small), in a private global slab otherwise
+        double *Hs = (NW == 2) ? dyn_lds + (size_t)(KP + 2) * ld : P.slab_H + (size_t)blockIdx.x * (size_t)n * n;
+        const double *S = P.siginv;
+        const bool sdiag = P.siginv_diag != 0;
+        const int64_t ticket = P.first + tk;
+        int tk_next = 0;
+        if (PERSIST && persist && tid == WAVE) tk_next = atomicAdd(P.ticket_ctr, 1) + (int)gridDim.x;
+        if (tid < 64) ss[tid] = 0.0;   // (read only after the document's first workgroup barrier)
         if (P.debug_flags & 8) {   // tests: nothing may depend on what an earlier workgroup left in the LDS
-            for (int q = threadIdx.x; q < P.lds_doubles; q += WAVE * NW) dyn_lds[q] = __builtin_nan("");
-            for (int q = threadIdx.x; q < KMAX + 1; q += WAVE * NW) { sv[q] = __builtin_nan(""); sw[q] = __builtin_nan(""); se[q] = __builtin_nan(""); }
+            for (int q = tid; q < P.lds_doubles; q += WAVE * NW) dyn_lds[q] = __builtin_nan("");
+            for (int q = tid; q < KMAX + 1; q += WAVE * NW) { sv[q] = __builtin_nan(""); sw[q] = __builtin_nan(""); se[q] = __builtin_nan(""); }
             __syncthreads();
         }
         const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
@@ -321,6 +448,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
         }
         const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
+        if (P.prof && tid == 0) P.prof[doc * PROF_SLOTS + 39] = (long long)wall_clock64();   // (100 MHz, the same on every XCD: the XCDs' shader clocks are not aligned; tools/slot_gaps.py)
         const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
 
@@ -340,6 +468,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         double csum = 0.0;
         bool bad = false;
         double breg[KR];   // beta_d[:, word] of word `wv*64 + lane` (KREG > 0)
+        if constexpr (PERSIST) {   // (the DMA form fills them under a lane mask: without a definition of their own at the top of a document the
+#pragma unroll                     // registers would count as live around the document loop's back edge -- 100 registers the set-up phase cannot use)
+            for (int k = 0; k < KR; ++k) breg[k] = 0.0;
+        }
         double c0 = 0.0, w0 = 0.0;
         const int wreg = wv * WAVE + lane;  // this lane's register-resident word
         constexpr bool COOP = !GLOBAL_SLAB && VPL == 1;   // LDS slab: its rows are gathered lane = topic, one coalesced run per word
@@ -437,6 +569,37 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 // g0 = beta_d @ (c / colsum) (stm.py:954), lane = topic: the leaves and the balanced tree of wave_sum() over the
                 // wave's 64 words -- the same additions in the same pairing as the cross-lane form, so the same bits.  Four
                 // words at a time (the scheduler would otherwise hoist a whole phase's LDS reads above beta_d's registers).
+#if STM_G0_PIPE
+                // software-pipelined: the operands of the next four words are read while the current four are multiplied and added (each
+                // step otherwise waits out its own round trip to the LDS, sixteen steps per wave)
+                double pa[2][4], pw[2][4], ps[2][4], pb[2][4];
+                auto g0_load = [&](int j0, int b) __attribute__((always_inline)) {
+                    const int wi0 = r0 + j0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pa[b][u] = stg[(j0 + u) * PITCH + kk]; pw[b][u] = wq[wi0 + u]; }
+                    if (wv == 1 && wi0 < NdL) {   // uniform: these words pair up with slab words wi0 .. (beyond the last: weight 0)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sr = wi0 + u < nsl ? wi0 + u : nsl - 1;
+                            ps[b][u] = slab[(size_t)sr * KP + kk]; pb[b][u] = svb[wi0 + u];
+                        }
+                    }
+                };
+                g0_load(0, 0);
+#pragma unroll
+                for (int j0 = 0; j0 < nr; j0 += 4) {
+                    const int wi0 = r0 + j0, qi = wi0 >> 2, b = (j0 >> 2) & 1;
+                    if (j0 + 4 < nr) g0_load(j0 + 4, b ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    double v[4];
+                    if (wv == 1 && wi0 < NdL) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { v[u] = pa[b][u] * pw[b][u]; v[u] = v[u] + ps[b][u] * pb[b][u]; }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = pa[b][u] * pw[b][u];
+                    }
+#else
 #pragma unroll
                 for (int j0 = 0; j0 < nr; j0 += 4) {
                     const int wi0 = r0 + j0, qi = wi0 >> 2;
@@ -454,6 +617,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
 #pragma unroll
                         for (int u = 0; u < 4; ++u) v[u] = stg[(j0 + u) * PITCH + kk] * wq[wi0 + u];
                     }
+#endif
                     const double Q = (v[0] + v[1]) + (v[2] + v[3]);
                     if ((qi & 1) == 0) Qc = Q;
                     else {
@@ -468,6 +632,9 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                             }
                         }
                     }
+#if STM_G0_PIPE
+                    asm volatile("" : "+v"(Qc), "+v"(Oc), "+v"(Sc), "+v"(Pc), "+v"(T));
+#endif
                 }
                 wait_lds();   // every read of the staging area has returned before the next rows are fetched into it
                 STM_WAVE_SYNC();
@@ -596,6 +763,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         }
         csum_all = wave_sum(csum);
         bool bad_all = wave_any(bad);
+        if (PERSIST && persist && tid == WAVE) tk_slot[tk_par] = tk_next;   // (the rows' waits have covered the add's return)
         if (NW == 2) {
             if (lane == 0) { xch_res[4 + wv] = csum_all; xch_cmd[1 + wv] = bad_all ? 1 : 0; }
             __syncthreads();
@@ -1561,6 +1729,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                     }
                     __syncthreads();  // (2) results posted
                 }
+                if (persist) continue;   // -> next_doc()
                 return;
             }
         }
@@ -1675,6 +1844,18 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
 #pragma unroll
             for (int r = 0; r < VPL; ++r) t += a[r] * b[r];
             return wave_sum(t);
+        };
+        auto dot_lane = [&](const double (&a)[VPL], const double (&b)[VPL]) __attribute__((always_inline)) -> double {   // dot()'s per-lane term
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) t += a[r] * b[r];
+            return t;
+        };
+        auto maxabs_lane = [&](const double (&a)[VPL]) __attribute__((always_inline)) -> double {   // maxabs()'s
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) t = nanmax(t, fabs(a[r]));
+            return t;
         };
         auto maxabs = [&](const double (&a)[VPL]) __attribute__((always_inline)) -> double {
             double t = 0.0;
@@ -1858,8 +2039,15 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 old_fval = fval;
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) g[r] = gv[r];
-                old_old_fval = old_fval + sqrt(dot(g, g)) / 2;
-                gnorm = maxabs(g);
+                if (STM_SM_BATCH) {
+                    double rs[1] = {dot_lane(g, g)}, rm[1] = {maxabs_lane(g)};
+                    wave_reduce_n(rs, rm);
+                    old_old_fval = old_fval + sqrt(rs[0]) / 2;
+                    gnorm = rm[0];
+                } else {
+                    old_old_fval = old_fval + sqrt(dot(g, g)) / 2;
+                    gnorm = maxabs(g);
+                }
                 st = S_OUTER_TOP;
             } [[fallthrough]];   // states that follow each other without an evaluation share one trip through the loop
             case S_OUTER_TOP: {
@@ -1877,7 +2065,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
 #pragma unroll
                     for (int r = 0; r < VPL; ++r) p[r] = -t[r];
                 }
-                derphi0 = dot(g, p);
+                if (!STM_SM_BATCH) derphi0 = dot(g, p);
                 {   // Lipschitz bounds of phi'(s) = df(x + s p).p along this direction (see S_W1_ITER):
                     //   phi''(s) = p^T [siginv + N_d (diag(theta_s) - theta_s theta_s^T)] p = p^T siginv p + N_d Var_{theta_s}([p, 0])
                     // (a) Var <= (max [p, 0] - min [p, 0])^2 / 4 for every theta                       -> Lb
@@ -1889,11 +2077,18 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         hi = nanmax(hi, p[r]); lo = nanmax(lo, -p[r]);
                         if (lane + WAVE * r < n) mx = nanmax(mx, x[r]);
                     }
-                    const double range = wave_nanmax(hi) + wave_nanmax(lo);
-                    const double pp = dot(p, p);
+                    double range, pp, m;
+                    if (STM_SM_BATCH) {   // g . p, p . p and the three maxima in one batch of reductions
+                        double rs[2] = {dot_lane(g, p), dot_lane(p, p)}, rm[3] = {hi, lo, mx};
+                        wave_reduce_n(rs, rm);
+                        derphi0 = rs[0]; pp = rs[1]; range = rm[0] + rm[1]; m = rm[2];
+                    } else {
+                        range = wave_nanmax(hi) + wave_nanmax(lo);
+                        pp = dot(p, p);
+                        m = wave_nanmax(mx);   // max of [x, 0]
+                    }
                     Lb = sig_lmax * pp + Ndoc * (0.25 * (range * range));
                     prange = range;
-                    const double m = wave_nanmax(mx);   // max of [x, 0]
                     double e[VPL], z = 0.0, e1 = 0.0;
 #pragma unroll
                     for (int r = 0; r < VPL; ++r) {
@@ -1901,16 +2096,26 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         z += e[r]; e1 += e[r] * p[r];
                     }
                     const double eK = exp(-m);          // the appended topic: p~ = 0
-                    const double Z = wave_sum(z) + eK, c = wave_sum(e1) / Z;
-                    double v2 = 0.0, psp = 0.0;
+                    double psp = 0.0;
+#pragma unroll
+                    for (int r = 0; r < VPL; ++r)
+                        if (sdiag && lane + WAVE * r < n) psp += (p[r] * sd[r]) * p[r];
+                    double Z, c, quad;
+                    if (STM_SM_BATCH) {
+                        double rs[3] = {z, e1, psp};
+                        wave_sum_n(rs);
+                        Z = rs[0] + eK; c = rs[1] / Z; quad = sdiag ? rs[2] : sig_lmax * pp;
+                    } else {
+                        Z = wave_sum(z) + eK; c = wave_sum(e1) / Z;
+                        quad = sdiag ? wave_sum(psp) : sig_lmax * pp;
+                    }
+                    double v2 = 0.0;
 #pragma unroll
                     for (int r = 0; r < VPL; ++r) {
                         const double dv = p[r] - c;
                         v2 += e[r] * (dv * dv);
-                        if (sdiag && lane + WAVE * r < n) psp += (p[r] * sd[r]) * p[r];
                     }
                     const double var0 = (wave_sum(v2) + eK * (c * c)) / Z;
-                    const double quad = sdiag ? wave_sum(psp) : sig_lmax * pp;
                     Lv = (quad + Ndoc * var0) * (1.0 + 1e-9);
                     // Third outcome-preserving test, before the first search spends an evaluation (k = 0: p = -df(x0), x0 the warm
                     // start left by the previous EM iteration).  The reference's df is not the gradient of f, and from EM iteration 4 on
@@ -2252,11 +2457,20 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                 ++k;
                 old_old_fval = phi0;
                 old_fval = acc_f;
-                gnorm = maxabs(g);
+                double pp_acc, rhok_inv;
+                if (STM_SM_BATCH) {   // max |g|, p . p and y . s in one batch of reductions
+                    double rs[2] = {dot_lane(p, p), dot_lane(y, s)}, rm[1] = {maxabs_lane(g)};
+                    wave_reduce_n(rs, rm);
+                    pp_acc = rs[0]; rhok_inv = rs[1]; gnorm = rm[0];
+                } else {
+                    gnorm = maxabs(g);
+                    pp_acc = 0.0; rhok_inv = 0.0;
+                }
                 if (gnorm <= gtol) { st = S_FINISH; break; }
-                if (acc_alpha * sqrt(dot(p, p)) <= 0.0) { st = S_FINISH; break; }  // xrtol = 0
+                if (!STM_SM_BATCH) pp_acc = dot(p, p);
+                if (acc_alpha * sqrt(pp_acc) <= 0.0) { st = S_FINISH; break; }  // xrtol = 0
                 if (!finite_d(old_fval)) { status = 2; st = S_FINISH; break; }
-                const double rhok_inv = dot(y, s);
+                if (!STM_SM_BATCH) rhok_inv = dot(y, s);
                 const double rhok = (rhok_inv == 0.0) ? 1000.0 : 1.0 / rhok_inv;
                 // H <- (I - rho s y^T) H (I - rho y s^T) + rho s s^T, expanded (H symmetric):
                 //   H - rho (s w^T + w s^T) + (rho^2 y^T w + rho) s s^T,  w = H y
@@ -2347,11 +2561,15 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // uniform stores (every lane writes the same word)
         if (P.prof && lane == 0) {
             P.prof[doc * PROF_SLOTS + 0] = t_init; P.prof[doc * PROF_SLOTS + 1] = t_eval; P.prof[doc * PROF_SLOTS + 2] = t_sm; P.prof[doc * PROF_SLOTS + 3] = t_upd;
+            // absolute begin / end of the document on the shader clock and the 100 MHz wall clock at its end (tools/slot_gaps.py: how many
+            // documents the chip really has in flight -- what the dispatch of one workgroup per document costs; [39] the wall clock at its begin)
+            P.prof[doc * PROF_SLOTS + 45] = t_begin; P.prof[doc * PROF_SLOTS + 46] = (long long)__builtin_readcyclecounter(); P.prof[doc * PROF_SLOTS + 47] = (long long)wall_clock64();
         }
         if (P.status) P.status[doc] = status;
         if (P.nit) P.nit[doc] = k;
         if (P.nfev) P.nfev[doc] = nfev;
         if (P.njev) P.njev[doc] = njev;
+        if (!persist) return;
     }
 }
 

@@ -128,6 +128,39 @@ __device__ __forceinline__ double wave_nanmax(double v) {
     const double m = lane_bcast(v, 63);
     return has_nan ? __builtin_nan("") : m;
 }
+// NS sums (s[]) and NM NaN-propagating maxima (m[]) at once: wave_sum()'s / wave_nanmax()'s steps, step by step on every value
+template <int NS, int NM>
+__device__ __forceinline__ void wave_reduce_n(double (&s)[NS], double (&m)[NM]) {
+    bool has_nan[NM];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) has_nan[q] = __any(m[q] != m[q]) != 0;
+#define STM_WR_STEP(CTRL)                                                                                          \
+    {                                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) { const double t = dpp_move<CTRL>(s[q]); s[q] += t; }        \
+        _Pragma("unroll") for (int q = 0; q < NM; ++q) { const double t = dpp_move<CTRL>(m[q]); m[q] = fmax(m[q], t); } \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(s[q]));                               \
+        _Pragma("unroll") for (int q = 0; q < NM; ++q) asm volatile("" : "+v"(m[q]));                               \
+    }
+#define STM_WR_BC(CTRL, ROWS)                                                                                      \
+    {                                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) { const double t = dpp_bcast<CTRL, ROWS>(s[q], 0.0); s[q] += t; }   \
+        _Pragma("unroll") for (int q = 0; q < NM; ++q) { const double t = dpp_bcast<CTRL, ROWS>(m[q], m[q]); m[q] = fmax(m[q], t); } \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) asm volatile("" : "+v"(s[q]));                               \
+        _Pragma("unroll") for (int q = 0; q < NM; ++q) asm volatile("" : "+v"(m[q]));                               \
+    }
+    STM_WR_STEP(DPP_XOR1)
+    STM_WR_STEP(DPP_XOR2)
+    STM_WR_STEP(DPP_HALF_MIRROR)
+    STM_WR_STEP(DPP_MIRROR)
+    STM_WR_BC(DPP_BCAST15, 0xa)
+    STM_WR_BC(DPP_BCAST31, 0xc)
+#undef STM_WR_STEP
+#undef STM_WR_BC
+#pragma unroll
+    for (int q = 0; q < NS; ++q) s[q] = lane_bcast(s[q], 63);
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { const double r = lane_bcast(m[q], 63); m[q] = has_nan[q] ? __builtin_nan("") : r; }
+}
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p) != 0; }
 // sqrt(d) and 1 / sqrt(d) together (d > 0): the coupled Goldschmidt iteration the compiler itself expands sqrt() into
 // carries h ~ 1 / (2 sqrt(d)) along, so the reciprocal costs one more multiplication instead of an IEEE division.
@@ -178,6 +211,32 @@ __device__ __forceinline__ double np_sign(double x) {
     return (double)((x > 0) - (x < 0));
 }
 __device__ __forceinline__ bool finite_d(double x) { return isfinite(x); }
+
+// N IEEE divisions num[q] / den[q] at once: the code generator's own expansion of an fp64 `/` (v_div_scale x 2, v_rcp, the refinement
+// of the reciprocal, v_div_fmas, v_div_fixup -- AMDGPUTargetLowering::LowerFDIV64), instruction for instruction, but stage by stage
+// over all N quotients: every result has the bits `num / den` has (tests/test_gpu_parity.py::test_interleaved_division...), and the N
+// dependent chains of ten instructions fill each other's latencies -- left to the compiler they run one after the other (DCSRCH's
+// dcstep makes up to seven divisions per call, three of them independent of each other at two points).
+template <int N>
+__device__ __forceinline__ void div_n(const double (&num)[N], const double (&den)[N], double (&out)[N]) {
+    double d0[N], r[N], e[N], n1[N], m[N], f4[N];
+    bool flag[N], unused;
+#define STM_DV(stmt) _Pragma("unroll") for (int q = 0; q < N; ++q) { stmt; }
+#define STM_DP(a) _Pragma("unroll") for (int q = 0; q < N; ++q) asm volatile("" : "+v"(a[q]));
+    STM_DV(d0[q] = __builtin_amdgcn_div_scale(num[q], den[q], false, &unused)) STM_DP(d0)
+    STM_DV(r[q] = __builtin_amdgcn_rcp(d0[q])) STM_DP(r)
+    STM_DV(e[q] = fma(-d0[q], r[q], 1.0)) STM_DP(e)
+    STM_DV(r[q] = fma(r[q], e[q], r[q])) STM_DP(r)
+    STM_DV(e[q] = fma(-d0[q], r[q], 1.0)) STM_DP(e)
+    STM_DV(n1[q] = __builtin_amdgcn_div_scale(num[q], den[q], true, &flag[q])) STM_DP(n1)
+    STM_DV(r[q] = fma(r[q], e[q], r[q])) STM_DP(r)
+    STM_DV(m[q] = n1[q] * r[q]) STM_DP(m)
+    STM_DV(f4[q] = fma(-d0[q], m[q], n1[q])) STM_DP(f4)
+    STM_DV(f4[q] = __builtin_amdgcn_div_fmas(f4[q], r[q], m[q], flag[q])) STM_DP(f4)
+    STM_DV(out[q] = __builtin_amdgcn_div_fixup(f4[q], den[q], num[q]))
+#undef STM_DV
+#undef STM_DP
+}
 
 // ---- natural logarithm, fdlibm e_log.c scheme (error < 1 ulp; 0.83 ulp measured over 2e7
 // arguments against a long-double reference): x = 2^k (1+f), sqrt(1/2) < 1+f < sqrt(2),

@@ -606,3 +606,80 @@ def test_integration_stub_runs_against_a_reference_shaped_object():
     bad.betaindex = np.ones(m.N, dtype=np.int64) * 0
     with pytest.raises(AssertionError):       # stm.py:534
         ns["E_step"](bad)
+
+
+# ------------------------------------------------------------------ where parity ends: the long-run regime
+def test_long_run_regime_of_config5_is_within_the_oracles_own_sensitivity(oracle, monkeypatch):
+    """Config 5's shape (content covariate, A = 2 levels of beta) scaled to 4000 documents and driven on the device until the
+    fit is in the long-run regime -- mean scipy `nit` >= 8: every document takes about ten BFGS iterations, and ten
+    iterations amplify a last-bit difference into one accepted step more or less.  One teacher-forced
+    E-step from that state, four ways:
+      (i)  the HIP path with and without its outcome-preserving line-search cuts (STM_DEBUG_FLAGS = 0 / 6) -- identical
+           status / nit / eta, bit for bit: the cuts are not what moves a document there;
+      (ii) the HIP path against the oracle, and the oracle against itself from a start moved by a relative 1e-13: the
+           number of documents whose nit / status differ between GPU and oracle must not exceed what the oracle's own
+           sensitivity to a perturbation of the last bits produces (with a floor of 1 % of the documents), and eta must
+           agree as well as the oracle agrees with itself."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    N, V, K, A = 4000, 10_000, 50, 2
+    syn = synthetic_corpus(N, V, K, n_words=150, seed=12345)
+    c = syn.corpus
+    aspect = np.random.default_rng(777).integers(0, A, size=N).astype(np.int32)
+    m = STM(documents=c, dictionary=None, content=True, K=K, X=syn.X, kappa_interactions=True, A=A, beta_index=aspect,
+            max_em_iter=200, sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    its, mean_nit = 0, 0.0
+    while its < 120 and mean_nit < 8.0:
+        m._em_iteration_resident()
+        its += 1
+        if its >= 10:
+            mean_nit = float(m.solver_diagnostics()["nit"].mean())
+    assert mean_nit >= 8.0, f"the fit never reached the long-run regime: mean nit {mean_nit:.2f} after {its} EM iterations"
+    beta, mu, eta = m.beta.copy(), m.mu.copy(), m.eta.copy()
+    m._preamble()
+    siginv, sigent = m.siginv.copy(), float(m.sigmaentropy)
+    res = {}
+    for flags in ("0", "6"):
+        monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
+        m.eta = eta.copy()
+        m._estep_device()
+        d = m.solver_diagnostics()
+        res[flags] = (d["status"].copy(), d["nit"].copy(), m.eta.copy(), d["nfev"].copy())
+    monkeypatch.delenv("STM_DEBUG_FLAGS")
+    assert np.array_equal(res["0"][0], res["6"][0]) and np.array_equal(res["0"][1], res["6"][1])
+    assert np.array_equal(res["0"][2], res["6"][2])                      # the same bits
+    assert res["6"][3].mean() > res["0"][3].mean()                       # (and the cuts did skip evaluations)
+    o = oracle.estep(c.indptr, c.indices, c.counts, beta, mu, eta, siginv, sigent, aspect=aspect, nthreads=0)
+    op = oracle.estep(c.indptr, c.indices, c.counts, beta, mu, eta * (1.0 + 1e-13), siginv, sigent, aspect=aspect, nthreads=0)
+    assert o["nit"].mean() >= 8.0
+    self_nit, self_status = int(np.sum(op["nit"] != o["nit"])), int(np.sum(op["status"] != o["status"]))
+    self_eta = float(np.max(np.abs(op["eta"] - o["eta"])))
+    gpu_nit, gpu_status = int(np.sum(res["0"][1] != o["nit"])), int(np.sum(res["0"][0] != o["status"]))
+    gpu_eta = float(np.max(np.abs(res["0"][2] - o["eta"])))
+    print(f"long-run regime after {its} EM iterations: mean nit {o['nit'].mean():.2f}; GPU vs oracle: {gpu_nit} nit / {gpu_status} status differ, "
+          f"eta {gpu_eta:.2e}; oracle vs oracle(1 + 1e-13): {self_nit} / {self_status}, eta {self_eta:.2e}")
+    floor = N // 100
+    assert gpu_nit <= max(2 * self_nit, floor) and gpu_status <= max(2 * self_status, floor // 4)
+    assert gpu_eta <= max(10 * self_eta, 1e-6)
+    m.close()
+
+
+# ------------------------------------------------------------------ config 4 as a corpus: the shards' statistics add up (VERDICT round 4, item 5)
+def test_config4_shape_cut_into_eight_shards_adds_up():
+    """BASELINE configs[3] (V = 50k, K = 100) is a document-sharded 8-GPU run: shard_bounds(indptr, 8), one E-step per shard,
+    one all-reduce.  On one GPU: the whole corpus' E-step against the eight shards run one after another through their own
+    handles -- every document's eta / status / nit / bound the same bits in its shard as in the whole corpus, the shards'
+    bound / sigma_ss / beta_ss sums equal to the whole corpus' to 1e-12, nnz balance within 1 %.  Here at 80k documents (two
+    E-steps: the cold start and the warm second one); tools/c4_corpus_shards.py runs the same check at the configuration's full
+    1M documents (profiles/r05_c4_corpus_shards.json)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c4_corpus_shards.py"), "80000", "50000", "100", "8"],
+                       capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1])
+    assert r.returncode == 0 and res["ok"], res
+    assert res["nnz_imbalance"] <= 0.01 and len(res["shards"]) == 8
+    for e in res["estep"]:
+        assert all(e["per_document_bits_equal"].values()), e
+        assert max(e["bound_rel"], e["sigma_ss_rel"], e["beta_ss_rel"]) <= 1e-12, e
