@@ -388,6 +388,8 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
 #ifndef STM_SOLVER_PERSIST_FORM
 #define STM_SOLVER_PERSIST_FORM 1
 #endif
+    // (The K > 64 direct-gather form, one wave per workgroup, was measured persistent too -- 242 VGPRs, no scratch, bit-identical: 8.79 ->
+    // 9.15 ms at config 4's share.  The dispatch of a one-wave workgroup is cheap; the loop is not.  It stays one workgroup per document.)
     constexpr bool PERSIST = NW == 2 && STM_SOLVER_PERSIST_FORM;
     const bool persist = PERSIST && P_arg.ticket_ctr != nullptr;
     // (two slots, alternating: wave 1 may be a document ahead of wave 0's read of the ticket -- never two, there are barriers in between)
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         const bool sdiag = P.siginv_diag != 0;
         const int64_t ticket = P.first + tk;
         int tk_next = 0;
-        if (PERSIST && persist && tid == WAVE) tk_next = atomicAdd(P.ticket_ctr, 1) + (int)gridDim.x;
+        if (PERSIST && persist && tid == WAVE * (NW - 1)) tk_next = atomicAdd(P.ticket_ctr, 1) + (int)gridDim.x;
         if (tid < 64) ss[tid] = 0.0;   // (read only after the document's first workgroup barrier)
         if (P.debug_flags & 8) {   // tests: nothing may depend on what an earlier workgroup left in the LDS
             for (int q = tid; q < P.lds_doubles; q += WAVE * NW) dyn_lds[q] = __builtin_nan("");
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         }
         csum_all = wave_sum(csum);
         bool bad_all = wave_any(bad);
-        if (PERSIST && persist && tid == WAVE) tk_slot[tk_par] = tk_next;   // (the rows' waits have covered the add's return)
+        if (PERSIST && persist && tid == WAVE * (NW - 1)) tk_slot[tk_par] = tk_next;   // (the rows' waits have covered the add's return)
         if (NW == 2) {
             if (lane == 0) { xch_res[4 + wv] = csum_all; xch_cmd[1 + wv] = bad_all ? 1 : 0; }
             __syncthreads();
@@ -803,6 +805,10 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
         // and an odd K's last lane -- which reads 8 bytes into the next row (or the padding behind betaT) -- drops its second
         // component at the store as well.
         double2 pre[DIRECT ? TWS : 1];
+        if constexpr (PERSIST && DIRECT) {   // (loaded under a lane mask: defined here, or the registers stay live around the document loop's back edge -- see breg)
+#pragma unroll
+            for (int j = 0; j < TWS; ++j) pre[j] = make_double2(0.0, 0.0);
+        }
         const bool has0 = 2 * lane < K, has1 = 2 * lane + 1 < K;
         auto tile_fetch = [&](int t0) __attribute__((always_inline)) {
             if constexpr (DIRECT) {
