@@ -62,6 +62,9 @@
 #define STM_DCSTEP_ILP 0   // dcstep: the independent divisions of a round at once (div_n).  Bit-identical and -0.5 % in the one-document-per-workgroup
                            // kernel; in the persistent form its extra live values tip the allocator over (51 instead of 17 spilled VGPRs, +15 %): off
 #endif
+#ifndef STM_PREFETCH
+#define STM_PREFETCH 1     // persistent two-wave form: wave 1 touches the next document's CSR / eta / mu lines while it waits for the first evaluation
+#endif
 #ifndef STM_FUSE_GROUP
 #define STM_FUSE_GROUP 4   // topics per scheduling group of the side-by-side three-sum passes (twelve chains)
 #endif
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
     const bool persist = PERSIST && P_arg.ticket_ctr != nullptr;
     // (two slots, alternating: wave 1 may be a document ahead of wave 0's read of the ticket -- never two, there are barriers in between)
     __shared__ int tk_slot[2];
+    __shared__ int pf_dump[PERSIST && STM_PREFETCH ? WAVE : 1];   // where the next document's prefetch lands (never read)
     int tk_par = 0;
     auto next_doc = [&]() __attribute__((always_inline)) -> int {
         __syncthreads();      // both waves are done with this document's LDS; the next ticket has long been parked in it
@@ -1685,6 +1689,34 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
             __syncthreads();
             if (wv == 1) {
                 if (lane < n) g0[0] += xch_gv[lane];
+                bool pf_pending = PERSIST && STM_PREFETCH;
+                auto prefetch_next = [&]() __attribute__((always_inline)) {
+                  if constexpr (PERSIST && STM_PREFETCH) {
+                    // The next document's header is known (its ticket came back during the set-up) and this wave has nothing to do while wave 0
+                    // digests the first evaluation: touch the lines that document's set-up reads first -- word ids, counts, eta, mu: cold, each
+                    // read once per E-step and otherwise two dependent trips to the HBM at the head of every document -- so that they wait
+                    // in the L2.  One instruction, a line per lane: lanes 0..15 ids, 16..47 counts, 48..55 eta, 56..63 mu.
+                    const int tkn = uni(tk_slot[tk_par]);   // (parked there during the set-up)
+                    if (persist && P.tick && (int64_t)tkn < P.count) {
+                        const int64_t tn = P.first + tkn;
+                        const int64_t h0 = scalar_load(P.tick + 2 * tn), h1 = scalar_load(P.tick + 2 * tn + 1);
+                        const int64_t docn = h1 & 0xffffffffLL;
+                        const int Ndn = (int)(h1 >> 32);
+                        const int li = lane < 16 ? lane : lane < 48 ? lane - 16 : (lane - 48) & 7;
+                        const char *base = lane < 16 ? reinterpret_cast<const char *>(P.indices + h0)
+                                         : lane < 48 ? reinterpret_cast<const char *>(P.counts + h0)
+                                         : lane < 56 ? reinterpret_cast<const char *>(P.eta + docn * n) : reinterpret_cast<const char *>(P.mu + docn * n);
+                        const int len = lane < 16 ? 4 * Ndn : lane < 48 ? 8 * Ndn : 8 * n;
+                        // (the first line may start anywhere inside a 128-byte line: one more line covers the tail)
+                        const int lead = (int)(reinterpret_cast<uintptr_t>(base) & 127);
+                        if (128 * li < len + lead) {
+                            const int off = 128 * li - lead;
+                            l2_prefetch_line(base + (off > 0 ? off : 0), lds_addr(pf_dump));
+                        }
+                    }
+                  }
+                  pf_pending = false;
+                };
                 for (;;) {
                     __syncthreads();  // (0) request posted: xch_cmd[0] and the trial point
                     const int cmd = uni(xch_cmd[0]);
@@ -1718,6 +1750,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         const double g0p = wave_sum(g0[0] * pl);
                         if (lane == 0) { xch_res[0] = part; xch_res[1] = q; xch_res[3] = g0p; xch_res[5] = d1; xch_res[6] = d2; }
                         __syncthreads();  // (2) results posted
+                        if (pf_pending) prefetch_next();
                         continue;
                     }
                     xt[0] = (lane < n) ? xch_xt[lane] : 0.0;
@@ -1734,6 +1767,7 @@ __global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ?
                         if (lane == 0) { xch_res[0] = part; xch_res[1] = q; }
                     }
                     __syncthreads();  // (2) results posted
+                    if (pf_pending) prefetch_next();
                 }
                 if (persist) continue;   // -> next_doc()
                 return;

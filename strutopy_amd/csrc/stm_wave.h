@@ -357,4 +357,13 @@ __device__ __forceinline__ void lds_dma16(const void *base, unsigned off, unsign
                  : "=&s"(keep), "=&s"(ex) : "v"(off), "s"(dst), "s"(base), "s"(mask) : "memory");
 }
 
+// A prefetch into the L2 with no register destination: global_load_lds_dword moves 4 bytes per enabled lane from the lane's own
+// 64-bit address to LDS byte address dst + 4 * lane (a dump nobody reads).  Nothing waits for it; a later vmcnt wait of the wave
+// merely counts it.  (The caller's branch around the call is the lane mask.)
+__device__ __forceinline__ void l2_prefetch_line(const void *addr, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(addr), "s"(dst) : "memory");
+}
+
 }  // namespace stm
