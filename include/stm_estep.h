@@ -58,10 +58,11 @@ int stm_device_info(stm_handle *h, char *name_out, int name_len, int *cu_count, 
  * beta_ss pass (8 bytes per entry on the device + a host copy of indices[]) -- INTEGRATION.md lists the memory. */
 int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr,
                    const int32_t *indices, const double *counts, const int32_t *aspect, int32_t A);
-/* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467.  2 <= K <= 128 (K <= 64: one topic per
+/* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467.  2 <= K <= 512 (K <= 64: one topic per
  * lane and the matrix-core post kernel; 64 < K <= 112: two topics per lane in the solver, two wavefronts per document
- * in the post step; 112 < K <= 128: two topics per lane throughout), K * V * 8 < 2^32 per level of beta (32-bit row
- * offsets): STM_ERR_INVALID beyond */
+ * in the post step; 112 < K <= 128: two topics per lane throughout; 128 < K <= 512: the general forms -- four / eight vector
+ * components per lane in the solver with the slab and the BFGS matrix in HBM, stm_post_any.h for the post step: correct, not
+ * tuned), K * V * 8 < 2^32 per level of beta (32-bit row offsets): STM_ERR_INVALID beyond */
 int stm_set_topics(stm_handle *h, int32_t K);
 int stm_put_beta(stm_handle *h, const double *beta /* [A][K][V] */);
 int stm_put_eta(stm_handle *h, const double *eta /* [N][K-1] */);
@@ -196,7 +197,7 @@ int stm_spectral_anchors(stm_handle *h, int32_t K, int32_t *anchor /* [K] out */
 int stm_spectral_project(stm_handle *h, int32_t K, const int32_t *anchor, double *q_out /* [Vk][K] */);
 /* recover_l2's per-term QPs on the device (stm.py:257-285): weights[i] = -argmin_{x <= 0} 1/2 x'Px + q_i'x with P = q[anchor],
  * one-hot rows for the anchor terms; the strictly convex QP is solved as the non-negative least-squares fit it is
- * (Lawson-Hanson active set), one thread per term.  K <= 128. */
+ * (Lawson-Hanson active set), one thread per term.  K <= 512. */
 int stm_spectral_weights(stm_handle *h, int32_t K, const int32_t *anchor, double *weights_out /* [Vk][K] */);
 int stm_spectral_release(stm_handle *h);
 

@@ -17,6 +17,7 @@
 #include "stm_post.h"
 #include "stm_post_big.h"
 #include "stm_post_big2.h"
+#include "stm_post_any.h"
 #include "stm_solver.h"
 
 namespace {
@@ -120,6 +121,7 @@ struct stm_handle {
     int V = 0, A = 1, maxNd = 0;
     std::vector<int64_t> h_indptr;
     std::vector<int32_t> h_len_sorted;   // document lengths in processing order (longest first)
+    int nd_max = 1;                      // words of the longest document
     int64_t *d_indptr = nullptr;
     int32_t *d_indices = nullptr, *d_aspect = nullptr, *d_order = nullptr;
     int64_t *d_tick = nullptr;           // per ticket of the longest-first order: {indptr[doc], doc | Nd << 32} (one scalar load instead of two dependent ones)
@@ -154,6 +156,7 @@ struct stm_handle {
     size_t red_len = 0;
     bool dma = false;            // two-wave solver with LDS-staged row gather (K == KREG = 50 or 64)
     bool direct = false;         // K > 64: rows re-gathered from betaT per pass instead of a per-document slab
+    bool any = false;            // K > 128 (or STM_POST_ANY=1): the general post kernel (stm_post_any.h), phi / nu by atomics
     bool big2 = false;           // 64 < K <= 112: the two-waves-per-document post kernel (stm_post_big2.h) + the word-major beta_ss pass
     // optional dumps
     double *d_phi = nullptr;
@@ -242,6 +245,8 @@ static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, b
     if (dma && kreg == 64) return stm::solver_kernel<1, 64, false, 2, 0, true>;
     if (vpl == 2 && direct) return stm::solver_kernel<2, 0, false, 1, 1>;   // 64 < K <= 128, rows re-gathered per pass
     if (vpl == 2) return global_slab ? stm::solver_kernel<2, 0, true> : stm::solver_kernel<2, 0, false>;   // 64 < K <= 128
+    if (vpl == 4) return stm::solver_kernel<4, 0, true>;   // 128 < K <= 256: the general form (slab and BFGS matrix in HBM)
+    if (vpl == 8) return stm::solver_kernel<8, 0, true>;   // 256 < K <= 512
     if (global_slab) return stm::solver_kernel<1, 0, true>;
     if (nw == 2) {
         switch (kreg) {
@@ -277,8 +282,8 @@ static int plan_solver(stm_handle *h) {
     h->nw = 1;
     if (mode == 0 || mode == 3) h->kreg = K <= 16 ? 16 : K <= 32 ? 32 : K <= 50 ? 50 : 64;
     if (mode == 0) h->nw = 2;
-    h->vpl = K > 64 ? 2 : 1;
-    if (h->vpl == 2) { h->kreg = 0; h->nw = 1; }   // two vector components per lane: beta_d in LDS / HBM only
+    h->vpl = K > 256 ? 8 : K > 128 ? 4 : K > 64 ? 2 : 1;
+    if (h->vpl >= 2) { h->kreg = 0; h->nw = 1; }   // two (four, eight) vector components per lane: beta_d in LDS / HBM only
     // rows through the LDS-DMA path: needs K == KREG (packed rows of K doubles are the slab's rows) and 32-bit row offsets
     h->dma = h->nw == 2 && K == h->kreg && (K == 50 || K == 64) && slab_row(K) == 2 * ((K / 2) | 1) &&
              ((size_t)h->A * h->V * K + 64) * sizeof(double) < ((size_t)1 << 32) && env_int("STM_SOLVER_DMA", 1) != 0;
@@ -303,7 +308,7 @@ static int plan_solver(stm_handle *h) {
     }
     auto per_cu = [&](int nd) -> int {
         const size_t b = ((lds_of(nd) + lds_static + 511) / 512) * 512;
-        if (mode == 2 || b > LDS_PER_CU) return 0;
+        if (mode == 2 || b > LDS_PER_CU || h->vpl > 2) return 0;   // (K > 128: the general form, slab in HBM)
         if (h->direct) return (int)std::min<size_t>((size_t)cmax, LDS_PER_CU / b);
         // K > 64: one wave per document and nothing to hide its latencies but other documents -- below four
         // documents per CU the HBM slab (occupancy bound by registers only) wins (C4: 93 / 25 / 43 -> 54 / 24 / 27 ms)
@@ -538,6 +543,8 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
     }
     h->h_len_sorted.resize((size_t)N);
     for (int64_t i = 0; i < N; ++i) h->h_len_sorted[(size_t)i] = (int32_t)(indptr[order[i] + 1] - indptr[order[i]]);
+    h->nd_max = 1;
+    for (int64_t i = 0; i < N; ++i) h->nd_max = std::max(h->nd_max, (int)h->h_len_sorted[(size_t)i]);
     // word-major order (stm_betass.h): a counting sort of the CSR positions by (level, word, document chunk); documents
     // ascend within a row.  The chunk size is fixed when K is known (stm_set_topics); until then the entries are kept
     // on the host.
@@ -552,7 +559,7 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr, c
 int stm_set_topics(stm_handle *h, int32_t K) {
     if (!h || h->V == 0) return fail(STM_ERR_INVALID, "stm_set_topics: set the corpus first");
     if (K < 2) return fail(STM_ERR_INVALID, "stm_set_topics: K must be >= 2");
-    if (K > 128) return fail(STM_ERR_INVALID, "stm_set_topics: K > 128 is not supported by this build");
+    if (K > stm::K_LIMIT) return fail(STM_ERR_INVALID, "stm_set_topics: K > " + std::to_string(stm::K_LIMIT) + " is not supported by this build");
     if (int rc = use_device(h)) return rc;
     if ((size_t)K * h->V * sizeof(double) >= ((size_t)1 << 32)) return fail(STM_ERR_INVALID, "stm_set_topics: one level of beta must stay below 4 GiB (32-bit row offsets)");
     h->K = K; h->n = K - 1;
@@ -586,8 +593,9 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = dalloc(&h->d_pd, N)) return rc;
     if (int rc = dalloc(&h->d_counters, 8)) return rc;
     if (int rc = dalloc(&h->d_err, 1 + SOLVER_TICKETS)) return rc;   // [0] the error flag, [1..] the ticket counters of the persistent solver launches
-    h->big2 = stm::post2_serves(K) && env_int("STM_POST_BIG2", 1) != 0;
-    if (K <= stm::PT || h->big2) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (post_big_kernel adds phi atomically)
+    h->any = K > 128 || env_int("STM_POST_ANY", 0) != 0;
+    h->big2 = !h->any && stm::post2_serves(K) && env_int("STM_POST_BIG2", 1) != 0;
+    if (!h->any && (K <= stm::PT || h->big2)) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (post_big_kernel adds phi atomically)
     // one block (one wave) per document.  The solver keeps beta_d on chip (64 words in registers,
     // the rest in LDS); launches are cut so every launch has one LDS size / occupancy class.
     if (int rc = plan_solver(h)) return rc;
@@ -813,35 +821,41 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
                         : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
         }
         const bool big2 = h->big2;                  // two waves per document (stm_post_big2.h)
-        big = K > stm::PT && !big2;                 // one wave per document, two topics per lane (stm_post_big.h): K > 112
-        rem_used = rem && K <= stm::PT;
+        const bool any = h->any;                    // any K: one workgroup per document, everything in HBM scratch (stm_post_any.h)
+        big = K > stm::PT && !big2 && !any;         // one wave per document, two topics per lane (stm_post_big.h): 112 < K <= 128
+        rem_used = rem && K <= stm::PT && !any;
         const int nbb = (n + 15) / 16;
         const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
                            : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
         PostFn pf2 = nullptr;
         const int pc2 = stm::post2_pc(K);
+        const int nwv2 = env_int("STM_POST_BIG2_WAVES", 2) == 4 ? 4 : 2;   // waves per document (stm_post_big2.h)
         if (big2) {
-            if (pc2 == 40) pf2 = dbg ? (nbb <= 4 ? stm::post_big2_kernel<4, 40, true> : stm::post_big2_kernel<5, 40, true>)
-                                     : (nbb <= 4 ? stm::post_big2_kernel<4, 40, false> : stm::post_big2_kernel<5, 40, false>);
-            else pf2 = dbg ? (nbb <= 5 ? stm::post_big2_kernel<5, 56, true> : nbb == 6 ? stm::post_big2_kernel<6, 56, true> : stm::post_big2_kernel<7, 56, true>)
-                           : (nbb <= 5 ? stm::post_big2_kernel<5, 56, false> : nbb == 6 ? stm::post_big2_kernel<6, 56, false> : stm::post_big2_kernel<7, 56, false>);
+#define STM_PB2(NBV, PCV) (nwv2 == 4 ? (dbg ? stm::post_big2_kernel<NBV, PCV, true, 4> : stm::post_big2_kernel<NBV, PCV, false, 4>) \
+                                     : (dbg ? stm::post_big2_kernel<NBV, PCV, true, 2> : stm::post_big2_kernel<NBV, PCV, false, 2>))
+            if (pc2 == 40) pf2 = nbb <= 4 ? STM_PB2(4, 40) : STM_PB2(5, 40);
+            else pf2 = nbb <= 5 ? STM_PB2(5, 56) : nbb == 6 ? STM_PB2(6, 56) : STM_PB2(7, 56);
+#undef STM_PB2
         }
-        pfn = big2 ? pf2 : big ? pfb : pf;
-        wg_threads = big2 ? 128u : 64u;
-        lds = (big2 ? (size_t)stm::post2_lds_map(K, pc2).total : big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
+        pfn = any ? (PostFn)stm::post_any_kernel : big2 ? pf2 : big ? pfb : pf;
+        wg_threads = any ? (unsigned)stm::ANY_BS : big2 ? 64u * (unsigned)nwv2 : 64u;
+        lds = (any ? stm::post_any_lds_doubles(K) : big2 ? (size_t)stm::post2_lds_map(K, pc2).total : big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, (int)wg_threads, lds));
-        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", 16)));
+        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", any ? 4 : 16)));
         grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
         if (big)    // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
             if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * n * n)) return rc;
+        if (any) {  // A, L, b and sqrt(c) of the document a workgroup is on (sized for the longest document)
+            if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * stm::post_any_scratch(K, h->nd_max))) return rc;
+        }
         // nu is summed per workgroup in a slab of its own (post_kernel, post_big2_kernel: plain read-modify-write, nrep = grid) or
         // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
-        nrep = big ? h->nrep : (int)grid;
+        nrep = (big || any) ? h->nrep : (int)grid;
         const int nbc = (n + 15) / 16;
         // accumulator-tile layout; with REM (post_kernel) the last column has a slot of its own instead of a block column of tiles
-        slab = big ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
+        slab = (big || any) ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
         if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
     }
     // the first stage of the two-stage reductions + the bound's block sums (reduce_copies grows it otherwise)
@@ -868,7 +882,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         sig_bound = std::max(sig_bound, r);
     }
     const size_t KV = (size_t)h->A * K * h->V;
-    const bool wm = K <= stm::PT || h->big2;    // phi through r_dw + the word-major pass (post_big_kernel adds it atomically)
+    const bool wm = !h->any && (K <= stm::PT || h->big2);    // phi through r_dw + the word-major pass (post_big_kernel adds it atomically)
     // ---- (A) the plan (estep_plan: every fallible host-side step), unless the caller made it already
     EstepPlan pl_own;
     if (!ready) { if (int rc = estep_plan(h, em_stage, pl_own)) return rc; }
@@ -922,6 +936,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
     pp.lds_doubles = (int)(lds / sizeof(double));
     pp.a_scratch = h->d_ascratch;
+    pp.nd_max = h->nd_max;
     pp.first = 0; pp.count = h->N;
     pp.rw = h->d_rw; pp.wm_slot = h->d_wm_pos;
 
@@ -1040,7 +1055,7 @@ int stm_last_kernel_ms(stm_handle *h, float *ms3) {
     // iteration) runs behind the E-step's last event and may still be in flight: the last COMPLETED pass stands in for it
     // (its time does not vary from one iteration to the next), 0 before any has completed.
     bss_time(h);
-    const float pass = (h->K <= 64 || h->big2) ? h->ms_bss : 0.0f;
+    const float pass = (!h->any && (h->K <= 64 || h->big2)) ? h->ms_bss : 0.0f;
     ms3[0] = h->ms[0]; ms3[1] = h->ms[1] + pass; ms3[2] = h->ms[2] + (h->last_deferred ? pass : 0.0f);
     return STM_OK;
 }

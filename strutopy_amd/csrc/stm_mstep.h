@@ -71,16 +71,18 @@ __global__ void set_mu_kernel(const double *X, const double *gamma, const double
     mu[q] = t;
 }
 
-// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j] (mu == nullptr: eta^T eta); n <= 128.
+// per-block partials of cov[i][j] = sum_d (eta-mu)[d][i] (eta-mu)[d][j] (mu == nullptr: eta^T eta); any n.
 // 256 threads as 16 x 16: thread (ty, tx) owns the 4 x 4 cells rows 64 blockIdx.z + 4 ty .., columns 64 blockIdx.y + 4 tx ..
 // (grid y = z = ceil(n / 64)) -- eight doubles read from the LDS tile per document and sixteen FMAs, where one column x
-// sixteen rows read seventeen; every cell still adds its documents in order.
+// sixteen rows read seventeen; every cell still adds its documents in order.  The tile holds the block's 64 row-side
+// components (first half) and its 64 column-side components (second half) of 32 documents.
 __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, const double *mu, int64_t N,
                                                          int n, double *part) {
     constexpr int TD = 32;  // documents per LDS tile
     __shared__ __attribute__((aligned(16))) double diff[TD][130];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int jc = 4 * tx + 64 * blockIdx.y, ib = 4 * ty + 64 * blockIdx.z;
+    const int ia = 4 * ty, ja = 64 + 4 * tx;   // where this thread's components sit in a tile row
     double acc[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, cons
             double v[TD * 128 / 256];
 #pragma unroll
             for (int it = 0; it < TD * 128 / 256; ++it) {
-                const int q = threadIdx.x + 256 * it, dd = q >> 7, i = q & 127;
+                const int q = threadIdx.x + 256 * it, dd = q >> 7, c = q & 127;
+                const int i = (c < 64 ? 64 * (int)blockIdx.z : 64 * (int)blockIdx.y - 64) + c;   // the component this tile cell holds
                 const bool in = dd < cnt && i < n;
                 const int64_t at = in ? (base + dd) * n + i : 0;
                 const double e = eta[at], m = mu ? mu[at] : 0.0;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void covariance_kernel(const double *eta, cons
         __syncthreads();
         for (int dd = 0; dd < cnt; ++dd) {
             const double2 *row = reinterpret_cast<const double2 *>(&diff[dd][0]);
-            const double2 a01 = row[ib >> 1], a23 = row[(ib >> 1) + 1], b01 = row[jc >> 1], b23 = row[(jc >> 1) + 1];
+            const double2 a01 = row[ia >> 1], a23 = row[(ia >> 1) + 1], b01 = row[ja >> 1], b23 = row[(ja >> 1) + 1];
             const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
             for (int u = 0; u < 4; ++u)

@@ -70,9 +70,24 @@ __host__ __device__ inline bool post2_serves(int K) { return K > 64 && K <= 112;
 // without a barrier in between (a clean matrix: no assemble) never rewrites a flag its partner has not read yet
 enum { X_CSUM = 0, X_LL = 2, X_Q = 4, X_DET = 6, X_FLAG = 8, X_BAD = 12 };
 
-template <int NB, int PC, bool DBG>
-__global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
-    constexpr int NT = NB * (NB + 1) / 2, NTW = (NT + 1) / 2;   // accumulator tiles: all / per wave (tile t belongs to wave t & 1)
+// NWV = 2 or 4 waves per document.  Four (round 5): waves 2 and 3 own no topics / matrix rows -- they take their share of everything that is
+// dealt out by tile, block row or block column (b b^T, the block-column updates, the inverse's block columns, nu) and wait at the barriers
+// through the rest; every element is still produced by the same operations in the same order, so the results are the two-wave kernel's bit
+// for bit.  With <= 128 registers a wave of every resident document sits on every SIMD (four documents per CU either way: the LDS).
+#ifndef STM_PB2_W4_OCC
+#define STM_PB2_W4_OCC 3   // waves per SIMD the four-wave form is compiled for: 3 -- <= 168 registers (64 spilled), three documents per CU: 21.8 ms at config 4's
+                           // share; 4 -- <= 128 registers, four documents per CU, but 536 spilled registers: 30.5 ms (the two-wave form: 19.9 ms)
+#endif
+template <int W0, int NWV, typename F>
+__device__ __forceinline__ void by_wave(int wv, F &&f) {   // f(integral_constant<int, wv>), wv known at compile time inside
+    if constexpr (W0 + 1 == NWV) f(std::integral_constant<int, W0>{});
+    else { if (wv == W0) f(std::integral_constant<int, W0>{}); else by_wave<W0 + 1, NWV>(wv, f); }
+}
+
+template <int NB, int PC, bool DBG, int NWV = 2>
+__global__ __launch_bounds__(64 * NWV, NWV == 2 ? 2 : STM_PB2_W4_OCC) void post_big2_kernel(PostParams P) {
+    static_assert(NWV == 2 || NWV == 4, "two or four waves per document");
+    constexpr int NT = NB * (NB + 1) / 2, NTW = (NT + NWV - 1) / NWV;   // accumulator tiles: all / per wave (tile t belongs to wave t % NWV)
     constexpr int PITCH = 2 * PC, QP = PC / 8;
     constexpr int NQW = TW * PC / 128;    // LDS-DMA instructions per wave and tile
     constexpr int TILE = TW * PITCH;
@@ -87,7 +102,8 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
     double *wpar = post2_lds + LM.wpar, *sex = post2_lds + LM.sex, *eth = post2_lds + LM.eth;
     double *sth = post2_lds + LM.sth, *sdv = post2_lds + LM.sdv;
     double *xch = post2_lds + LM.xch;
-    double *cb = post2_lds + LM.cb + 16 * wv;
+    double *cb = post2_lds + LM.cb + 16 * (wv & 1);
+    const bool rowwave = NWV == 2 || wv < 2;   // (uniform) the waves whose lanes own topics / matrix rows
     const double *S = P.siginv;
     const bool sdiag = P.siginv_diag != 0;
     // this workgroup's own sum of nu, accumulator-tile layout (tile (b, bj), b <= bj, at bj (bj + 1) / 2 + b)
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
         relane();
         STM_WG_SYNC();   // the previous document's readers of the LDS are done
         if (DBG && (P.debug_flags & 16)) {   // nothing may depend on what an earlier document or kernel left in the LDS
-            for (int q = gl; q < P.lds_doubles; q += 2 * WAVE) post2_lds[q] = __builtin_nan("");
+            for (int q = gl; q < P.lds_doubles; q += NWV * WAVE) post2_lds[q] = __builtin_nan("");
             STM_WG_SYNC();
         }
         const int64_t ticket = P.first + tk;
@@ -128,15 +144,19 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
         // word ids (lane w < 16: word t0 + w, both waves) and counts / word-major slots (lane 8 w' + e of wave wv: word
         // t0 + 8 wv + w'); lanes beyond the document repeat its last word (a valid row for the fetch)
         auto load_ids = [&](int t0, int &idx, double &c, int &slot) __attribute__((always_inline)) {
-            const int wi = t0 + lane, wc = t0 + 8 * wv + (lane >> 3), last = Nd - 1;
-            idx = P.indices[p0 + (wi < last ? wi : last)];
-            c = P.counts[p0 + (wc < last ? wc : last)];
-            slot = P.wm_slot[p0 + (wc < last ? wc : last)];
+            idx = 0; c = 0.0; slot = 0;
+            if (rowwave) {
+                const int wi = t0 + lane, wc = t0 + 8 * wv + (lane >> 3), last = Nd - 1;
+                idx = P.indices[p0 + (wi < last ? wi : last)];
+                c = P.counts[p0 + (wc < last ? wc : last)];
+                slot = P.wm_slot[p0 + (wc < last ? wc : last)];
+            }
         };
         // the 16 rows of a tile, betaT -> LDS: chunk c = 64 q + lane (16 bytes) is chunk c mod PC of word c / PC; this wave
         // issues the instructions q = wv, wv + 2, ...  Chunks beyond the topics of a row repeat its last one: finite, and
         // the sums meet them with zeros.
         auto tile_fetch = [&](int idxv, int buf) __attribute__((always_inline)) {
+            if (!rowwave) return;
             unsigned off[NQW];
             int id[NQW];
 #pragma unroll
@@ -182,8 +202,10 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             sex[gl] = ex;                          // zeros from K on
             eth[gl] = isk ? ex * ths : 0.0;        // theta . (beta * exp(eta~)) = sum_k beta_k (exp(eta~)_k theta_k), stm.py:1088-1094
         }
-        sth[gl] = isk ? ths : 0.0;
-        sdv[gl] = isn ? eta_i - mu_i : 0.0;
+        if (rowwave) {
+            sth[gl] = isk ? ths : 0.0;
+            sdv[gl] = isn ? eta_i - mu_i : 0.0;
+        }
         tile_fetch(idx0, 0);
         STM_WG_SYNC();
         // (eta - mu)^T siginv (eta - mu) (stm.py:1098-1099): nothing later depends on it, and region 0 is free for its vector now
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                 q = t * d;
             }
             q = wave_sum(q);
-            if (lane == 0) xch[X_Q + wv] = q;
+            if (lane == 0 && rowwave) xch[X_Q + wv] = q;
         }
 
         if (DBG && P.prof) tp[1] = (long long)__builtin_readcyclecounter();
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             load_ids(t0 + 2 * TW, idx2, c2, sl2);
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[0] += cy - cy0; cy0 = cy; }
             // -- 1. per-word sums, lane = (word 8 wv + (lane >> 3), eighth lane & 7 of the row: chunks e, e + 8, ...)
-            {
+            if (rowwave) {
                 const int w = 8 * wv + (lane >> 3), e = lane & 7;
                 const double2 *T2 = reinterpret_cast<const double2 *>(T) + w * PC + e;
                 const double2 *E2 = reinterpret_cast<const double2 *>(sex) + e;
@@ -315,10 +337,10 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                         for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                             for (int bj = bi; bj < NB; ++bj, ++t)
-                                if ((t & 1) == W) acc[t >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s & 1][bi], f[s & 1][bj], acc[t >> 1], 0, 0, 0);
+                                if (t % NWV == W) acc[t / NWV] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[s & 1][bi], f[s & 1][bj], acc[t / NWV], 0, 0, 0);
                     }
                 };
-                if (wv == 0) tiles(std::integral_constant<int, 0>{}); else tiles(std::integral_constant<int, 1>{});
+                by_wave<0, NWV>(wv, tiles);
             }
             if (DBG && P.prof) { const long long cy = __builtin_readcyclecounter(); tq[3] += cy - cy0; }
             idx0 = idx1; c0 = c1; sl0 = sl1; idx1 = idx2; c1 = c2; sl1 = sl2;
@@ -330,7 +352,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
         if (wave_any(sbad || (isk && !(rowc >= 0.0)))) atomicMax(P.err_flag, 7 /* STM_ERR_PHI */);   // stm.py:1117
         {
             const double cs = wave_sum(csum), lls = wave_sum(ll);
-            if (lane == 0) { xch[X_CSUM + wv] = cs; xch[X_LL + wv] = lls; }
+            if (lane == 0 && rowwave) { xch[X_CSUM + wv] = cs; xch[X_LL + wv] = lls; }
         }
         STM_WG_SYNC();
         const double Ndoc = (double)(long long)(xch[X_CSUM] + xch[X_CSUM + 1]);
@@ -345,13 +367,13 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                 for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                     for (int bj = bi; bj < NB; ++bj, ++t)
-                        if ((t & 1) == W) {
+                        if (t % NWV == W) {
                             const double thj = sth[bj * 16 + fr];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[t >> 1][r] = acc[t >> 1][r] - Ndoc * (sth[bi * 16 + fq + 4 * r] * thj);
+                            for (int r = 0; r < 4; ++r) acc[t / NWV][r] = acc[t / NWV][r] - Ndoc * (sth[bi * 16 + fq + 4 * r] * thj);
                         }
             };
-            if (wv == 0) fold(std::integral_constant<int, 0>{}); else fold(std::integral_constant<int, 1>{});
+            by_wave<0, NWV>(wv, fold);
         }
         STM_WG_SYNC();   // the tiles and the vectors of region 0 are done with: the matrix takes their place
 
@@ -367,20 +389,20 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                 for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
                     for (int bj = bi; bj < NB; ++bj, ++t)
-                        if ((t & 1) == W) {
+                        if (t % NWV == W) {
                             const int j = bj * 16 + fr, jc = j < n ? j : nm1;
                             const int rsj = RS(jc);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int i = bi * 16 + fq + 4 * r, ic = i < n ? i : nm1;
-                                double h = acc[t >> 1][r];
+                                double h = acc[t / NWV][r];
                                 if (!sdiag && i != j) h += S[(size_t)ic * n + jc];
                                 const bool st = j < n && (bi != bj || i <= j);
                                 M[st ? rsj + i : MDUMP] = h;
                             }
                         }
             };
-            if (wv == 0) part(std::integral_constant<int, 0>{}); else part(std::integral_constant<int, 1>{});
+            by_wave<0, NWV>(wv, part);
         };
 
         double diagA = 1.0, Ldiag = 1.0;
@@ -397,7 +419,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             const bool slow = wave_any(isn && !(diagA > 1e-260 && diagA < 1e270));   // (see sqrt_and_rsqrt_pivot)
             double *flag = xch + X_FLAG + 2 * (chol_calls & 1);
             ++chol_calls;
-            if (lane == 0) flag[wv] = (neg ? 1.0 : 0.0) + (slow ? 2.0 : 0.0);
+            if (lane == 0 && rowwave) flag[wv] = (neg ? 1.0 : 0.0) + (slow ? 2.0 : 0.0);
             if (isn) M[RS(gl) + gl] = diagA;
             STM_WG_SYNC();
             const double f0 = flag[0], f1 = flag[1];
@@ -415,7 +437,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                     const int bc = J0 + fr, bcc = bc < n ? bc : nm1;
                     const double *brow = M + RS(bcc);                       // row of L_p* for the B operands (L_pk^T)
 #pragma unroll 1
-                    for (int bi = p + wv; bi < NB; bi += 2) {
+                    for (int bi = p + wv; bi < NB; bi += NWV) {
                         const int ar = bi * 16 + fr, arc = ar < n ? ar : nm1;
                         const double *arow = M + RS(arc);
                         int dst[4];
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                 // shadow of those rows in its lanes 48 .. 63.  Rows above the panel shadow its first row, rows beyond n the
                 // last one (never stored).
                 const int wp = J0 >> 6;
-                if (wv >= wp) {
+                if (wv >= wp && rowwave) {
                     const bool owner = wv == wp;
                     const int pl0 = owner ? (J0 & 63) : 48;                       // lane of the panel's first row
                     const bool shadow = !owner && lane >= 48;
@@ -597,7 +619,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
         // ---- bound (stm.py:1068-1101); X's diagonal 1 / L_ii goes to the triangle's free diagonal cells
         {
             const double det = wave_sum(isn ? log(Ldiag) : 0.0);
-            if (lane == 0) xch[X_DET + wv] = det;
+            if (lane == 0 && rowwave) xch[X_DET + wv] = det;
         }
         const double Rdiag = 1.0 / Ldiag;
         if (isn) M[RS(gl) + gl] = Rdiag;
@@ -619,7 +641,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             //     the rows of L are independent of x, so their loads run ahead of the substitution chain, and every store
             //     comes after every load (one instruction stream per wave, and the two waves own different blocks).
             __builtin_amdgcn_s_setprio(2);   // substitution chains, then dependent MFMA chains: ahead of the SIMD's other wave
-            {
+            if (rowwave) {
                 const int c = gl & 15, rb = gl & ~15;
                 const bool has = rb < n;
                 const int rbc = has ? rb : 0;                         // lanes beyond the matrix shadow block 0 (nothing is stored)
@@ -675,8 +697,8 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
             {
                 v4d xcol[NB];
 #pragma unroll 1
-                for (int c0 = 0; c0 + 1 < NB; c0 += 2) {
-                    const int c = c0 + (wv ^ ((c0 >> 1) & 1));
+                for (int c0 = 0; c0 + 1 < NB; c0 += NWV) {
+                    const int c = c0 + (NWV == 2 ? (wv ^ ((c0 >> 1) & 1)) : wv);
                     const int bc = c * 16 + fr;
                     if (c + 1 < NB) {
                         // k outermost: step k first closes X_kc (its sum is complete: the rows above are done), then adds L_rk X_kc to the
@@ -766,7 +788,7 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
         // additions is the order of the workgroup's documents).  Cells beyond n are exact zeros.
         double *nu_doc = (DBG && P.nu_out) ? P.nu_out + (size_t)doc * n * n : nullptr;
         if (upper) {   // nu = diag(1 / L_ii^2): element (i, i) sits in tile (b, b) at r = ((i & 15) - fq) / 4, lane = (fq, fr = i & 15)
-            for (int bb = wv; bb < NB; bb += 2) {
+            for (int bb = wv; bb < NB; bb += NWV) {
                 const int i = bb * 16 + fr, r = (fr - fq) >> 2;
                 if (((fr - fq) & 3) == 0 && fr >= fq && i < n) {
                     const double rdi = M[RS(i) + i];
@@ -805,8 +827,8 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
                         for (int bj = 0; bj <= R; ++bj)
 #pragma unroll
                             for (int bb = 0; bb <= bj; ++bb) {
-                                if (((bj * (bj + 1) / 2 + bb) & 1) == W)
-                                    an[(bj * (bj + 1) / 2 + bb) >> 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[bb], g[bj], an[(bj * (bj + 1) / 2 + bb) >> 1], 0, 0, 0);
+                                if ((bj * (bj + 1) / 2 + bb) % NWV == W)
+                                    an[(bj * (bj + 1) / 2 + bb) / NWV] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[bb], g[bj], an[(bj * (bj + 1) / 2 + bb) / NWV], 0, 0, 0);
                             }
                     }
                 }
@@ -815,24 +837,24 @@ __global__ __launch_bounds__(128, 2) void post_big2_kernel(PostParams P) {
 #pragma unroll
                     for (int bb = 0; bb <= bj; ++bb) {
                         const int t = bj * (bj + 1) / 2 + bb;
-                        if ((t & 1) != W) continue;
+                        if (t % NWV != W) continue;
                         double *slab = sig_acc + (size_t)t * 4 * WAVE + lane;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // fire-and-forget: the cell belongs to this wave alone (no contention, program order from one document
                             // to the next), so the sum is the same every run -- and no old value has to be fetched and held
-                            unsafeAtomicAdd(slab + r * WAVE, an[t >> 1][r]);
+                            unsafeAtomicAdd(slab + r * WAVE, an[t / NWV][r]);
                             if (DBG && nu_doc) {
                                 const int i = bb * 16 + fq + 4 * r, j = bj * 16 + fr;
                                 if (i < n && j < n) {
-                                    nu_doc[(size_t)i * n + j] = an[t >> 1][r];
-                                    nu_doc[(size_t)j * n + i] = an[t >> 1][r];
+                                    nu_doc[(size_t)i * n + j] = an[t / NWV][r];
+                                    nu_doc[(size_t)j * n + i] = an[t / NWV][r];
                                 }
                             }
                         }
                     }
             };
-            if (wv == 0) nu_tiles(std::integral_constant<int, 0>{}); else nu_tiles(std::integral_constant<int, 1>{});
+            by_wave<0, NWV>(wv, nu_tiles);
         }
         if (DBG && P.prof && gl == 0) {
             tp[7] = (long long)__builtin_readcyclecounter();

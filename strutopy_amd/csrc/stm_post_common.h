@@ -42,7 +42,9 @@ struct PostParams {
     long long *prof;       // optional [N][PROF_SLOTS] (shared with the solver's): [32..39] post-kernel phase cycles
     double *rw;            // post_kernel (K <= 64): [nnz] r_dw of stm_betass.h, word-major ...
     const int32_t *wm_slot; // ... at wm_slot[CSR position]
+    int nd_max;            // post_any_kernel: words of the longest document (sizes the per-workgroup scratch behind a_scratch)
 };
+constexpr int K_LIMIT = 512;   // topics: eight vector components per lane in the solver's general form (stm_solver.h, VPL = 8)
 
 // A Cholesky pivot that is only the rounding left over from cancelling the diagonal entry counts as failed (as in the
 // oracle): make_pd can leave an exactly singular matrix (n = 2: always when both diagonals are raised), and the sign of such a

@@ -351,7 +351,7 @@ __device__ __forceinline__ bool quadmin(double a, double fa, double fpa, double 
 // first update), read back as ds_read_b128 by the lane that owns the word -- and while the rows are there, g0 is summed with
 // lane = topic (two LDS reads, a multiply and an add per word) instead of 50 cross-lane reductions.
 template <int VPL, int KREG, bool GLOBAL_SLAB, int NW = 1, int DIRECT = 0, bool DMA = false>
-__global__ __launch_bounds__(64 * NW, (VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P_arg) {
+__global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 1 : KREG > 0 ? 2 : 4)) void solver_kernel(SolverParams P_arg) {
     constexpr int KMAX = 64 * VPL;
     constexpr int VREG = (KREG > 0) ? WAVE * NW : 0;  // words held in registers
     constexpr int KR = (KREG > 0) ? KREG : 2;

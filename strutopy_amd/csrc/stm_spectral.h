@@ -216,7 +216,8 @@ __global__ __launch_bounds__(64) void anchor_project_kernel(const double *Q, int
 // with a check of the QP's KKT conditions on its result; *nbad counts the terms that fail it (iteration cap, or a violated
 // dual left behind by a ban): the reference's quadprog raises on a P that is not positive definite, stm_spectral_weights
 // reports these the same way instead of returning weights that are not the minimiser.
-constexpr int NNLS_KMAX = 128;
+constexpr int NNLS_KMAX = 512;   // (= K_LIMIT, stm_post_common.h)
+template <int KMAX>   // 128 or NNLS_KMAX: the per-thread vectors live in scratch memory, sized at compile time
 __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t *anchor, int K, int Vk, double *fac /* [Vk][K][K] */,
                                                    double *weights /* [Vk][K] */, int32_t *nbad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,9 +232,9 @@ __global__ __launch_bounds__(64) void nnls_kernel(const double *q, const int32_t
     const double *qi = q + (size_t)i * K;
     // P = M M^T = the rows `anchor` of q (q[a][k] = Q[a] . Q[anchor[k]])
     auto Pm = [&](int a, int b) -> double { return q[(size_t)anchor[a] * K + b]; };
-    double w[NNLS_KMAX], z[NNLS_KMAX], rhs[NNLS_KMAX];
-    int idx[NNLS_KMAX];
-    bool inS[NNLS_KMAX], banned[NNLS_KMAX];
+    double w[KMAX], z[KMAX], rhs[KMAX];
+    int idx[KMAX];
+    bool inS[KMAX], banned[KMAX];
     double qmax = 0.0;
     for (int k = 0; k < K; ++k) { w[k] = 0.0; inS[k] = false; banned[k] = false; qmax = fmax(qmax, fabs(qi[k])); }
     const double tol = 1e-13 * fmax(qmax, 1e-300) * K;

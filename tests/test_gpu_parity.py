@@ -129,6 +129,73 @@ def test_shapes_at_the_limits(oracle, K, nd_max):
     _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
 
 
+def _random_case(rng, K, V, N, nd_max, dense):
+    docs = [np.sort(rng.choice(V, int(rng.integers(1, nd_max + 1)), replace=False)) for _ in range(N)]
+    docs[0] = np.arange(nd_max)
+    indptr = np.concatenate([[0], np.cumsum([len(d) for d in docs])]).astype(np.int64)
+    indices = np.concatenate(docs).astype(np.int32)
+    counts = rng.integers(1, 6, size=len(indices)).astype(np.float64)
+    beta = rng.gamma(0.1, 1, size=(K, V)); beta /= beta.sum(axis=1)[:, None]
+    n = K - 1
+    mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
+    Bm = rng.normal(size=(n, n)); sigma = Bm @ Bm.T + np.eye(n)
+    return indptr, indices, counts, beta, mu, eta, sigma
+
+
+@pytest.mark.parametrize("K,nd_max", [(129, 90), (160, 300), (256, 70), (257, 40), (300, 50)])
+def test_more_than_128_topics(oracle, K, nd_max):
+    """K > 128 (the reference takes any K, stm.py:311-329): the solver's general form with four / eight vector components per
+    lane (slab and BFGS matrix in HBM) and post_any_kernel (stm_post_any.h) -- 129 | 256 | 257 are the edges of the two."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(K)
+    indptr, indices, counts, beta, mu, eta, sigma = _random_case(rng, K, 900, 40, nd_max, False)
+    siginv, sigent = oracle.preamble(sigma)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K}")
+    if K <= 160:
+        args = (indptr, indices, counts, beta, mu, eta, np.linalg.inv(sigma), sigent)
+        _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} dense")
+
+
+@pytest.mark.parametrize("K,nd_max", [(2, 40), (3, 30), (18, 300), (50, 130), (100, 200), (128, 90)])
+def test_general_post_kernel_is_a_second_implementation(oracle, monkeypatch, K, nd_max):
+    """STM_POST_ANY=1 routes every K through post_any_kernel (plain loops in HBM scratch, no matrix cores, no LDS matrix): it must
+    agree with the oracle wherever the matrix-core kernels do, and with them (same solver, so eta is the same bits)."""
+    from strutopy_amd.engine import estep_host
+    rng = np.random.default_rng(500 + K)
+    indptr, indices, counts, beta, mu, eta, sigma = _random_case(rng, K, 700, 50, nd_max, False)
+    siginv, sigent = oracle.preamble(sigma)
+    args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
+    fast = estep_host(*args)
+    monkeypatch.setenv("STM_POST_ANY", "1")
+    slow = estep_host(*args)
+    _check(slow, oracle.estep(*args, nthreads=0), f"K={K} general post kernel")
+    assert np.array_equal(slow["eta"], fast["eta"]) and np.array_equal(slow["pd_path"], fast["pd_path"])
+    assert np.max(np.abs(slow["bound_doc"] - fast["bound_doc"]) / np.abs(fast["bound_doc"])) <= 1e-10
+    assert _rel(slow["sigma_ss"], fast["sigma_ss"]) <= 1e-9 and _rel(slow["beta_ss"], fast["beta_ss"]) <= 1e-10
+
+
+def test_general_post_kernel_matrices_per_document(monkeypatch):
+    """H, L and nu of post_any_kernel against the reference's own (toy_ctm / edge goldens: PD ladder paths included)."""
+    from strutopy_amd.engine import HipEstepEngine
+    monkeypatch.setenv("STM_DEBUG_DUMP", "1")
+    monkeypatch.setenv("STM_POST_ANY", "1")
+    for name in ("toy_ctm", "edge"):
+        g = load_golden(name)
+        e = HipEstepEngine(0)
+        e.set_corpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+        e.set_topics(int(g["K"]))
+        e.put_beta(g["beta0"]); e.put_mu(g["it0_mu_in"]); e.put_eta(g["it0_eta_in"])
+        e.estep(g["it0_siginv"], float(g["it0_sigmaentropy"]))
+        hess, chol, nu = e.debug_mats()
+        phi = e.get_phi_last()
+        e.close()
+        assert _rel(hess, g["it0_hess"]) <= 1e-7, name
+        assert _rel(chol, g["it0_chol"]) <= 1e-7, name
+        assert _rel(nu, g["it0_nu"]) <= 1e-6, name
+        assert _rel(phi, g["it0_phi_last"]) <= 1e-7, name
+
+
 @pytest.mark.parametrize("K,nd_max", [(17, 70), (34, 50), (49, 70), (50, 90), (64, 90), (100, 60), (128, 40)])
 def test_post_kernels_ignore_stale_lds(oracle, monkeypatch, K, nd_max):
     """STM_POST_DEBUG=16 fills the post kernel's LDS with NaN before every document (STM_DEBUG_FLAGS=8: the solver's, per

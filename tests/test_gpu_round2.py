@@ -238,6 +238,69 @@ def test_k_above_64_statistics_are_run_to_run_identical(K):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("K", [70, 100])
+def test_k_above_64_four_waves_per_document_equal_two(K, monkeypatch):
+    """post_big2_kernel<..., NWV = 4> (STM_POST_BIG2_WAVES=4): waves 2 and 3 only take tiles, block rows and block columns off the two
+    row-owning waves -- every element keeps its operations and their order, so at an equal number of workgroups (the nu slabs
+    are per workgroup: three documents per CU for both) the statistics agree with the two-wave form bit for bit."""
+    from strutopy_amd.corpus import synthetic_corpus
+    from strutopy_amd.engine import HipEstepEngine
+    c = synthetic_corpus(3000, 4000, K, n_words=120, seed=K).corpus
+    beta = reference_beta0(K, c.V)
+    n = K - 1
+    rng = np.random.default_rng(K)
+    eta0 = rng.normal(0, 0.2, size=(c.N, n))
+    siginv = np.eye(n) / 20.0 + 0.001          # dense: the assembly adds its off-diagonals
+    sigent = 0.5 * n * np.log(20.0)
+    monkeypatch.setenv("STM_POST_MAX_WG_PER_CU", "3")
+    runs = []
+    for waves in ("2", "4"):
+        monkeypatch.setenv("STM_POST_BIG2_WAVES", waves)
+        e = HipEstepEngine(0)
+        e.set_corpus(c.indptr, c.indices, c.counts, c.V)
+        e.set_topics(K)
+        e.put_beta(beta); e.put_mu(np.zeros((c.N, n))); e.put_eta(eta0)
+        bound = e.estep(siginv, sigent)
+        runs.append((bound, e.get_beta_ss(), e.get_sigma_ss(), e.get_eta(), e.get_theta(), e.get_bound_docs()))
+        e.close()
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("K", [130, 200])
+def test_more_than_128_topics_device_mstep_and_resident_em(K):
+    """K > 128 through the device M-step: the covariance kernel's 64 x 64 blocks beyond the second (n = 129: a third block row of
+    one component), the moments, and a resident EM fit whose first bound equals the plain E-step's."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    from strutopy_amd.engine import HipEstepEngine
+    syn = synthetic_corpus(300, 600, K, n_words=60, seed=K)
+    c = syn.corpus
+    n = K - 1
+    rng = np.random.default_rng(K)
+    eta = rng.normal(0, 0.5, size=(c.N, n)); mu = rng.normal(0, 0.5, size=(c.N, n))
+    e = HipEstepEngine(0)
+    e.set_corpus(c.indptr, c.indices, c.counts, c.V)
+    e.set_topics(K)
+    e.put_eta(eta); e.put_mu(mu)
+    cov = e.covariance()
+    e.close()
+    want = (eta - mu).T @ (eta - mu)
+    assert np.max(np.abs(cov - want)) <= 1e-11 * np.max(np.abs(want))
+    m = STM(documents=c, dictionary=None, content=False, K=K, X=syn.X, kappa_interactions=False, max_em_iter=3,
+            sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    beta0, eta0, mu0 = m.beta.copy(), m.eta.copy(), m.mu.copy()
+    m.expectation_maximization(saving=False)
+    assert len(m.last_bounds) == 3 and np.all(np.isfinite(m.last_bounds))
+    m2 = STM(documents=c, dictionary=None, content=False, K=K, X=syn.X, kappa_interactions=False, max_em_iter=3,
+             sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+    assert np.array_equal(m2.beta, beta0) and np.array_equal(m2.eta, eta0) and np.array_equal(m2.mu, mu0)
+    m2.E_step()
+    assert m2.bound == pytest.approx(m.last_bounds[0], rel=1e-10)
+    m.close(); m2.close()
+
+
 def test_content_covariate_at_k50_against_the_reference_itself():
     """BASELINE config 4's shape (K = 50, A = 2) against the reference: E-steps teacher-forced, then the resident loop's
     device M-step for per-level beta (beta_normalise_topics_kernel) against the reference's M-step results."""

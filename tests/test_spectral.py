@@ -232,6 +232,40 @@ def test_device_qp_with_a_dependent_anchor_row_is_still_a_minimiser():
 
 
 @pytest.mark.gpu
+def test_device_qp_beyond_128_topics_is_a_minimiser():
+    """K = 140 anchors (nnls_kernel<512>: per-thread vectors of up to K_LIMIT entries): every term's weights satisfy the KKT
+    conditions of recover_l2's QP (stm.py:257-285), and a fit with init_type="spectral" runs at that K."""
+    from strutopy_amd import STM
+    from strutopy_amd.corpus import synthetic_corpus
+    from strutopy_amd.engine import HipEstepEngine
+    from strutopy_amd.spectral import gram_inputs, kept_terms
+    K = 140
+    syn = synthetic_corpus(3000, 1200, K, n_words=80, seed=140)
+    c = syn.corpus
+    e = HipEstepEngine(0)
+    wprob, keep = kept_terms(c, 5000)
+    e.spectral_gram(c.N, len(keep), gram_inputs(c, keep))
+    anchor = np.array(e.spectral_anchors(K), dtype=np.float64)
+    assert len(np.unique(anchor)) == K
+    q = e.spectral_project(anchor)
+    w = e.spectral_weights(anchor)
+    P = q[np.intp(anchor)]
+    free = np.ones(len(q), dtype=bool); free[np.intp(anchor)] = False
+    grad = w @ P - q
+    scale = np.abs(q).max()
+    assert w.min() >= 0 and np.isfinite(w).all()
+    assert grad[free].min() >= -1e-7 * scale and np.abs(grad[free][w[free] > 0]).max() <= 1e-7 * scale
+    e.spectral_release()
+    e.close()
+    m = STM(documents=c, dictionary=None, content=False, K=K, X=syn.X, kappa_interactions=False, max_em_iter=2,
+            sigma_prior=0, convergence_threshold=1e-5, init_type="spectral")
+    assert np.isfinite(m.beta).all() and m.beta.min() >= 0 and m.beta.shape == (K, c.V)
+    m.expectation_maximization(saving=False)
+    assert np.all(np.isfinite(m.last_bounds))
+    m.close()
+
+
+@pytest.mark.gpu
 def test_stm_with_spectral_init_on_the_gpu():
     """src/05_train.py's configuration in miniature: init_type="spectral", then EM on the device."""
     from strutopy_amd import STM
