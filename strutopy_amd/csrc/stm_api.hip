@@ -107,6 +107,12 @@ __global__ void copy_out_kernel(const double *src, double *dst, size_t cnt) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < cnt) dst[q] = src[q];
 }
+// ... and the device error flag with it (a 4-byte hipMemcpyAsync of its own is a blit kernel and a gap on the stream: 11 us per EM iteration)
+__global__ void copy_out_err_kernel(const double *src, double *dst, size_t cnt, const int32_t *err, int32_t *err_dst) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < cnt) dst[q] = src[q];
+    if (q == 0) *err_dst = *err;
+}
 
 }  // namespace
 
@@ -909,6 +915,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t) * (1 + SOLVER_TICKETS), h->stream));
+    // (the nu slabs are zeroed HERE, in front of the solver, so that nothing stands between the solver and the post kernel)
+    if (run_post) HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
     if (!wm || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));   // (the word-major pass writes every cell)
 
     stm::SolverParams sp{};
@@ -971,7 +979,6 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->bss_deferred = false; h->last_deferred = false;
     if (run_post) {
-        HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
         hipLaunchKernelGGL(pfn, dim3((unsigned)grid), dim3(wg_threads), lds, h->stream, pp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
