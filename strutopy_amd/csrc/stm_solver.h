@@ -2284,6 +2284,12 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                 st = S_W1_ITER;
             } break;
             case S_W1_ITER: {  // DCSRCH._iterate with (stp, f, g) = (alpha, fval, dval)
+#ifdef STM_SM_PROF   // a build for tools/solver_prof.py: where one DCSRCH step's cycles go (profile slots 40..43: tests / dcstep / interval + clip / cuts)
+                long long smc = (long long)__builtin_readcyclecounter();
+#define STM_SM_LAP(q) if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) P.prof[doc * PROF_SLOTS + 40 + (q)] += now_ - smc; smc = now_; }
+#else
+#define STM_SM_LAP(q)
+#endif
                 ++w1_calls;
                 double stp = alpha;
                 const double f = fval, gd = dval;
@@ -2302,6 +2308,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                     break;
                 }
                 if (task == 2) { st = S_W2_START; break; }
+                STM_SM_LAP(0)
                 {
                     // modified function (psi) in stage 1, plain one otherwise: selects, not branches
                     const bool mod = (stage == 1 && f <= fx && f > ftest);
@@ -2320,6 +2327,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                     gx = mod ? out.dx + gt : out.dx;
                     gy = mod ? out.dy + gt : out.dy;
                 }
+                STM_SM_LAP(1)
                 if (brackt) {
                     if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
                     width1 = width;
@@ -2337,6 +2345,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                     (brackt && stmax - stmin <= xtol * stmax))
                     stp = stx;
                 if (!finite_d(stp) || w1_calls >= 100) { st = S_W2_START; break; }
+                STM_SM_LAP(2)
                 // Outcome-preserving shortcut for the tail of a failing search.  Once the minimiser is
                 // bracketed every later trial step lies in [0, smax], smax = max(stx, sty) (the interval
                 // only shrinks; an out-of-range step is replaced by stx).  phi'(s) = df(x + s p).p has
@@ -2362,6 +2371,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                 }
                 alpha = stp; need_f = true; need_g = true; want_eval = true;
                 st = S_W1_ITER;
+                STM_SM_LAP(3)
             } break;
             case S_W2_GOT_G: {
                 const double derphi_a1 = dval;

@@ -40,6 +40,8 @@ for it in range(ITS):
         print("   K > 64 set-up sweep cycles/doc: wait for the tile + store %.0f, next tile's fetch issue %.0f, g0 %.0f, per-word sums %.0f, v %.0f" % tuple(out[:, 40:45].mean(0)))
     else:
         print("   one evaluation on wave 0, cycles/doc: post + barrier 0 %.0f, max/exp %.0f, barrier 1 %.0f, lse + data term %.0f, barrier 2 %.0f" % tuple(out[:, 40:45].mean(0)))
+        if os.environ.get("STM_SM_PROF_LIB"):   # a library built with -DSTM_SM_PROF: the same slots hold one DCSRCH step's pieces instead
+            print("   DCSRCH steps (S_W1_ITER), cycles/doc: tests %.0f, dcstep %.0f, interval + clip %.0f, cuts + request %.0f" % tuple(out[:, 40:44].mean(0)))
     names = ["INIT_DONE", "OUTER_TOP", "W1_START", "W1_ITER", "W2_START", "W2_FIRST", "W2_TOP", "W2_GOT_G", "W2_GOT_F",
              "ZOOM_TOP", "ZOOM_GOT_F", "ZOOM_GOT_G", "MOMENTS", "ACCEPT", "ACCEPT2", "FINISH"]
     pn = ["prologue", "word tiles", "H assembly", "Cholesky ladder", "bound", "inverse", "nu"]
