@@ -34,6 +34,63 @@ def _default_engine(device):
     return HipEstepEngine(device)
 
 
+def lasso_from_moments(Sxx, Sxe, syy, n_samples, alpha=1.0, tol=1e-4, max_iter=1000):
+    """sklearn.linear_model.Lasso(alpha, fit_intercept=True).fit(X, eta).coef_ (stm.py:677-681) from the centred moments
+    Sxx = Xc^T Xc (p x p), Sxe = Xc^T eta_c (p x n) and syy = diag(eta_c^T eta_c) (n): cyclic coordinate descent on the Gram
+    matrix -- sklearn's own `enet_coordinate_descent_gram` (its `precompute` form of the solver the reference runs): the
+    objective 1/(2 N) |y - X w|^2 + alpha |w|_1 scaled by N, coefficients from zero, one target at a time in sklearn, all
+    targets side by side here (each with its own stopping test: largest coordinate update below `tol`, then the duality gap
+    below tol * |y|^2).  X and eta enter through these moments only, so document shards need nothing beyond what the
+    iteration's all-reduce already carries.  Returns coef (n x p)."""
+    Q = np.ascontiguousarray(Sxx, dtype=np.float64)
+    q = np.ascontiguousarray(Sxe, dtype=np.float64)
+    p, n = q.shape
+    a = float(alpha) * float(n_samples)
+    W = np.zeros((p, n))
+    H = np.zeros((p, n))                     # Q @ W, kept up to date
+    y2 = np.asarray(syy, dtype=np.float64)
+    gap_tol = tol * y2
+    active = np.ones(n, dtype=bool)
+    diag = np.diag(Q)
+    for it in range(max_iter):
+        idx = np.flatnonzero(active)
+        if idx.size == 0:
+            break
+        w_max = np.zeros(idx.size)
+        d_w_max = np.zeros(idx.size)
+        Wa, Ha, qa = W[:, idx], H[:, idx], q[:, idx]
+        for ii in range(p):
+            if diag[ii] == 0.0:
+                continue
+            w_ii = Wa[ii].copy()
+            Ha -= Q[:, ii][:, None] * w_ii[None, :]
+            tmp = qa[ii] - Ha[ii]
+            w_new = np.sign(tmp) * np.maximum(np.abs(tmp) - a, 0.0) / diag[ii]
+            Wa[ii] = w_new
+            Ha += Q[:, ii][:, None] * w_new[None, :]
+            d_w_max = np.maximum(d_w_max, np.abs(w_new - w_ii))
+            w_max = np.maximum(w_max, np.abs(w_new))
+        W[:, idx], H[:, idx] = Wa, Ha
+        with np.errstate(divide="ignore", invalid="ignore"):
+            check = (w_max == 0.0) | (d_w_max / w_max < tol) | (it == max_iter - 1)
+        if not check.any():
+            continue
+        c = idx[check]
+        Wc, Hc, qc = W[:, c], H[:, c], q[:, c]
+        q_dot_w = np.sum(Wc * qc, axis=0)
+        dual = np.max(np.abs(qc - Hc), axis=0)
+        r2 = y2[c] + np.sum(Wc * Hc, axis=0) - 2.0 * q_dot_w
+        big = dual > a
+        const = np.where(big, a / np.where(big, dual, 1.0), 1.0)
+        gap = np.where(big, 0.5 * (r2 + r2 * const ** 2), r2)
+        gap = gap + a * np.sum(np.abs(Wc), axis=0) - const * y2[c] + const * q_dot_w
+        active[c[gap < gap_tol[c]]] = False
+    if active.any():
+        import warnings
+        warnings.warn(f"lasso_from_moments: {int(active.sum())} target(s) did not reach the duality-gap tolerance in {max_iter} sweeps")
+    return W.T.copy()
+
+
 def encode_covariates(X, comm=None):
     """The covariate preparation of update_mu (stm.py:656-671): 2-D, one-hot unless already 0/1.
 
@@ -359,9 +416,7 @@ class STM:
         if self.model not in ("STM", "CTM"):
             raise ValueError("model_type must be 'STM' or 'CTM'")
         use_reg = self.model == "STM"
-        if use_reg and self.mode == "lasso":
-            raise NotImplementedError("mode='lasso' needs the full eta on the host: use E_step()/M_step()")
-        if use_reg and self.mode not in ("ols", "ridge") and not getattr(self, "_mode_notice", False):
+        if use_reg and self.mode not in ("ols", "ridge", "lasso") and not getattr(self, "_mode_notice", False):
             # the reference's own fallback (stm.py:696-700)
             print("Need to specify the estimation mode of prevalence covariate coefficients. Uses default 'ols'.")
             self._mode_notice = True
@@ -403,6 +458,8 @@ class STM:
             Sxe = Xte - Ntot * np.outer(xbar, ebar)
             if self.mode == "ridge":
                 coef = np.linalg.solve(Sxx + 0.1 * np.eye(p), Sxe)          # Ridge(alpha=0.1)
+            elif self.mode == "lasso":                                       # Lasso(alpha=1), stm.py:677-681
+                coef = lasso_from_moments(Sxx, Sxe, np.diag(ete) - Ntot * ebar * ebar, Ntot).T
             else:
                 coef = np.linalg.pinv(Sxx, rcond=1e-12, hermitian=True) @ Sxe  # minimum-norm OLS
             self.gamma = coef.T                                              # (K-1) x p, stm.py:703
@@ -440,7 +497,7 @@ class STM:
         first_start_time = time.time()
         logger.info(f"Fit STM for {self.K} topics")
         for _iteration in range(100):
-            if resident and not (self.model == "STM" and self.mode == "lasso"):
+            if resident:
                 self._em_iteration_resident()
             else:
                 beta_ss, sigma_ss = self.E_step()

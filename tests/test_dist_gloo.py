@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="binary", init="random", outdir=None):
+def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="binary", init="random", outdir=None, mode="ols"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       OMP_NUM_THREADS="2")
     os.environ.pop("STM_RDZV_PORT", None)
@@ -45,11 +45,12 @@ def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="
     X = _covariate(g, xkind)
     m = STM(documents=full.slice(lo, hi), dictionary=None, content=False, K=int(g["K"]), X=X[lo:hi],
             kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
-            init_type=init, model_type=model_type, comm=comm, engine=OracleEngine(nthreads=2))
+            init_type=init, model_type=model_type, mode=mode, comm=comm, engine=OracleEngine(nthreads=1))
     assert m.N_total == full.N
     m.expectation_maximization(saving=outdir is not None, output_dir=outdir)
+    d = m.solver_diagnostics()
     q.put((rank, lo, hi, list(m.last_bounds), m.sigma.copy(), m.beta.copy(), m.mu.copy(), m.eta.copy(),
-           getattr(m, "gamma", None)))
+           getattr(m, "gamma", None), d["nit"].copy(), d["nfev"].copy()))
     if outdir is not None:
         np.save(os.path.join(outdir, f"rank{rank}_theta"), m.theta)     # what this rank held when save_model ran
     comm.barrier()
@@ -101,8 +102,10 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind, tmp_
     full = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
     ref = STM(documents=full, dictionary=None, content=False, K=int(g["K"]), X=_covariate(g, xkind),
               kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
-              init_type="random", model_type=model_type, engine=OracleEngine())
+              init_type="random", model_type=model_type, engine=OracleEngine(nthreads=1))
     ref.expectation_maximization(saving=True, output_dir=out1)
+    rd = ref.solver_diagnostics()
+    searched = np.concatenate([(r[9] != rd["nit"][r[1]:r[2]]) | (r[10] != rd["nfev"][r[1]:r[2]]) for r in res])   # documents whose last search ran differently
     # save_model on the sharded fit (stm.py:1120-1149, called from stm.py:880): rank 0 alone wrote the reference's files, with
     # the N x K arrays of the WHOLE corpus -- exactly the two shards' rows in corpus order -- and the single-process fit's
     # file set / shapes / dtypes
@@ -120,23 +123,24 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind, tmp_
             if f == "X.npy":
                 assert np.array_equal(a, b)         # the covariate rows, in corpus order
             elif f in ("eta_hat.npy", "theta_hat.npy"):
-                # per document: the oracle adds phi with OpenMP atomics, so beta's last bits differ from run to run, and once in a
-                # while a document's last line search accepts one step more or less ("noise-level accept / reject")
+                # per document: two shards add beta_ss in another order than one process does (1e-16), and once in a while a
+                # document's last line search accepts one step more or less for it ("noise-level accept /
+                # reject") -- such a row must show it in the solver's own counts; every other row holds the tight tolerance
                 rows = ~np.all(np.isclose(a, b, rtol=1e-7, atol=1e-8), axis=1)
-                assert rows.sum() <= 2 and np.allclose(a, b, rtol=0, atol=1e-3), (f, int(rows.sum()))
+                assert rows.sum() <= 2 and not np.any(rows & ~searched) and np.allclose(a, b, rtol=0, atol=1e-3), (f, int(rows.sum()))
             else:
                 assert np.allclose(a, b, rtol=1e-6, atol=1e-8), f
     with open(os.path.join(out2, "lower_bound.pickle"), "rb") as fh:
         assert pickle.load(fh) == res[0][3]
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == full.N
-    for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma in res:
+    for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma, _nit, _nfev in res:
         # the ELBO is the all-reduced sum; the second iteration sees the first one's 1e-16 summation-order differences amplified
         assert np.isclose(bounds[0], ref.last_bounds[0], rtol=1e-12) and np.allclose(bounds, ref.last_bounds, rtol=1e-9)
         assert np.allclose(sigma, ref.sigma, rtol=1e-8, atol=1e-12)
         assert np.allclose(beta, ref.beta, rtol=1e-8, atol=1e-14)
         assert np.allclose(mu, ref.mu[lo:hi], atol=1e-9)
         off = ~np.all(np.isclose(eta, ref.eta[lo:hi], rtol=0, atol=1e-8), axis=1)      # (a noise-level accept / reject, see above)
-        assert off.sum() <= 2 and np.allclose(eta, ref.eta[lo:hi], atol=1e-3)
+        assert off.sum() <= 2 and not np.any(off & ~searched[lo:hi]) and np.allclose(eta, ref.eta[lo:hi], atol=1e-3)
         if model_type == "STM":
             assert np.allclose(gamma, ref.gamma, rtol=1e-7, atol=1e-10)
     # both ranks finish the (replicated) M-step with identical global parameters
@@ -144,6 +148,46 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind, tmp_
     # and the trace still matches the reference's golden trace
     for it in range(iters if xkind == "binary" else 1):
         assert res[0][3][it] == pytest.approx(float(g[f"it{it}_bound"]), rel=1e-8)
+
+
+def test_two_rank_lasso_fit_equals_single_process():
+    """mode="lasso" (stm.py:677-681) on a document-sharded fit: the coefficients come from coordinate descent on the centred
+    Gram matrix (strutopy_amd.stm.lasso_from_moments), i.e. from the all-reduced moments alone -- two ranks, each holding a
+    different subset of a three-level covariate's levels, end with the single-process fit, whose host M-step in turn is
+    sklearn's Lasso on the full eta (what the reference calls)."""
+    import torch.multiprocessing as mp
+    from _oracle_engine import OracleEngine
+    from strutopy_amd.corpus import PackedCorpus
+    from strutopy_amd.stm import STM
+    case, iters = "c1_k10", 2
+    g = load_golden(case)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, "STM", iters, q, "gloo", "sorted3", "random", None, "lasso")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = PackedCorpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
+    out = {}
+    for resident in (True, False):     # resident: lasso from the moments; host: sklearn.linear_model.Lasso on eta (stm.py:677-681)
+        ref = STM(documents=full, dictionary=None, content=False, K=int(g["K"]), X=_covariate(g, "sorted3"), kappa_interactions=False,
+                  max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12, init_type="random", model_type="STM", mode="lasso",
+                  engine=OracleEngine(nthreads=1))
+        ref.expectation_maximization(saving=False, resident=resident)
+        out[resident] = ref
+    ref, host = out[True], out[False]
+    assert np.allclose(ref.gamma, host.gamma, rtol=1e-6, atol=1e-9) and np.allclose(ref.sigma, host.sigma, rtol=1e-7, atol=1e-10)
+    assert np.allclose(ref.last_bounds, host.last_bounds, rtol=1e-9)
+    for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma, _nit, _nfev in res:
+        assert gamma.shape == (int(g["K"]) - 1, 3)
+        assert np.allclose(bounds, ref.last_bounds, rtol=1e-9)
+        assert np.allclose(gamma, ref.gamma, rtol=1e-7, atol=1e-10) and np.allclose(sigma, ref.sigma, rtol=1e-8, atol=1e-12)
+        assert np.allclose(beta, ref.beta, rtol=1e-8, atol=1e-14) and np.allclose(mu, ref.mu[lo:hi], atol=1e-9)
+    assert np.array_equal(res[0][4], res[1][4]) and np.array_equal(res[0][5], res[1][5])
 
 
 def test_two_rank_fit_with_spectral_init_equals_single_process():
@@ -177,7 +221,7 @@ def test_two_rank_fit_with_spectral_init_equals_single_process():
               kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
               init_type="spectral", model_type="STM", engine=OracleEngine())
     ref.expectation_maximization(saving=False)
-    for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma in res:
+    for rank, lo, hi, bounds, sigma, beta, mu, eta, gamma, _nit, _nfev in res:
         # the shards' gram matrices are added in a different order than a single process adds the documents (1e-16), the
         # per-term QPs and two EM iterations amplify that: the first ELBO (a function of the initial beta alone) pins the
         # initialisation, the state after the fit is compared at the amplified level

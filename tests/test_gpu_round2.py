@@ -32,7 +32,7 @@ def _corpus(g):
 @pytest.mark.parametrize("resident", [False, True])
 def test_mstep_branches_against_the_reference_on_the_gpu(tag, mode, sp, resident):
     """mode="ridge" / "lasso" and sigma_prior = 0.5 through the HIP path: host M-step and the resident loop (ridge: the
-    moment-based solve on the reduced statistics; lasso: falls back to the host fit) against the reference's run."""
+    moment-based solve on the reduced statistics; lasso: coordinate descent on the centred Gram matrix) against the reference's run."""
     import _mstep_modes
     _mstep_modes.run(load_golden("mstep_modes"), tag, mode, sp, resident)
 

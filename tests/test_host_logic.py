@@ -292,7 +292,7 @@ def test_content_covariate_levels(resident):
 @pytest.mark.parametrize("resident", [False, True])
 def test_mstep_branches_against_the_reference(tag, mode, sp, resident):
     """mode="ridge" / "lasso" and sigma_prior > 0 (stm.py:678-689, 721-728) against the reference's own two EM iterations;
-    resident=True takes the moment-based ridge solve / shrinkage of the device loop (lasso: the host fallback)."""
+    resident=True takes the moment-based ridge solve / lasso coordinate descent / shrinkage of the device loop."""
     import _mstep_modes
     _mstep_modes.run(load_golden("mstep_modes"), tag, mode, sp, resident, engine=OracleEngine())
 
