@@ -19,6 +19,7 @@
 #include "stm_post_big2.h"
 #include "stm_post_any.h"
 #include "stm_solver.h"
+#include "stm_epilogue.h"
 
 namespace {
 
@@ -29,6 +30,9 @@ thread_local std::string g_err;
 // columns when the model is set up, grown by stm_put_covariates when X is wider
 constexpr size_t moments_len(int p, int n) { return 1 + (size_t)p + n + (size_t)p * p + (size_t)p * n + (size_t)n * n; }
 constexpr size_t round64(size_t x) { return (x + 63) / 64 * 64; }
+constexpr int MOM_BLOCKS = stm::EPI_COV_BLOCKS;   // partial-sum blocks of the moment / covariance passes (4 per CU)
+// ... of the regression moments: fewer when X is wide (Lr ~ p^2 doubles per block; at most 128 MB of partials)
+inline int mom_blocks(size_t Lr) { return (int)std::max<size_t>(16, std::min<size_t>(MOM_BLOCKS, ((size_t)1 << 24) / std::max<size_t>(Lr, 1))); }
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -222,7 +226,7 @@ static int use_device(stm_handle *h) {
 }
 
 // out[nn] = sum of the nblocks copies part[b][nn], fixed order; many copies: in two stages of RED_Y block rows
-constexpr int RED_Y = 32, BOUND_BLOCKS = 128;
+constexpr int RED_Y = stm::EPI_RED_Y, BOUND_BLOCKS = stm::EPI_BOUND_BLOCKS;
 static int reduce_copies(stm_handle *h, const double *part, int nblocks, int nn, double *out) {
     const unsigned gx = (unsigned)((nn + 63) / 64);
     if (nblocks < 4 * RED_Y) {
@@ -872,7 +876,8 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
     return STM_OK;
 }
 
-static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentropy, bool em_stage, bool defer_bss = false, const EstepPlan *ready = nullptr) {
+static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentropy, bool em_stage, bool defer_bss = false, const EstepPlan *ready = nullptr,
+                         bool with_moments = false) {
     NEED_MODEL(h);
     if (!h->beta_set) return fail(STM_ERR_INVALID, "stm_estep: beta has not been set");
     if (!siginv) return fail(STM_ERR_INVALID, "stm_estep: siginv is NULL");
@@ -903,21 +908,25 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     const int dbg_stage = pl.dbg_stage;
 
     // ---- (B) the E-step, enqueued on the handle's stream
-    if (em_stage) {
-        double *st = (double *)h->stage_sig;
-        memcpy(st, siginv, sizeof(double) * (size_t)n * n);
-        HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
-    } else if (h->stage && sizeof(double) * (size_t)n * n <= stm_handle::STAGE_BYTES / 2) {   // second half of the staging buffer
-        double *st = (double *)((char *)h->stage + stm_handle::STAGE_BYTES / 2);
-        memcpy(st, siginv, sizeof(double) * (size_t)n * n);
-        HIP_TRY(hipMemcpyAsync(h->d_siginv, st, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
-    } else {
-        HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+    // one launch in front of the solver (stm_epilogue.h): siginv out of a pinned staging area, the error flag + ticket counters and
+    // the nu slabs zeroed (they are zeroed HERE so that nothing stands between the solver and the post kernel)
+    {
+        const double *sig_src = nullptr;
+        if (em_stage) {
+            sig_src = (const double *)h->stage_sig;
+        } else if (h->stage && sizeof(double) * (size_t)n * n <= stm_handle::STAGE_BYTES / 2) {   // second half of the staging buffer
+            sig_src = (const double *)((char *)h->stage + stm_handle::STAGE_BYTES / 2);
+        }
+        if (sig_src) memcpy((void *)sig_src, siginv, sizeof(double) * (size_t)n * n);
+        else HIP_TRY(hipMemcpyAsync(h->d_siginv, siginv, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, h->stream));
+        const size_t nslab = run_post ? (size_t)nrep * slab : 0;
+        const size_t nbss = (!wm || h->nnz == 0) ? KV : 0;   // (the word-major pass writes every cell)
+        const size_t work = std::max<size_t>((nslab + nbss) / 2, (size_t)n * n);
+        const unsigned hb = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (work + 1023) / 1024));
+        hipLaunchKernelGGL(stm::estep_head_kernel, dim3(hb), dim3(256), 0, h->stream, sig_src, h->d_siginv, n * n, h->d_err, 1 + SOLVER_TICKETS,
+                           h->d_sigma_part, nslab, h->d_beta_ssT, nbss);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(int32_t) * (1 + SOLVER_TICKETS), h->stream));
-    // (the nu slabs are zeroed HERE, in front of the solver, so that nothing stands between the solver and the post kernel)
-    if (run_post) HIP_TRY(hipMemsetAsync(h->d_sigma_part, 0, sizeof(double) * (size_t)nrep * slab, h->stream));
-    if (!wm || h->nnz == 0) HIP_TRY(hipMemsetAsync(h->d_beta_ssT, 0, sizeof(double) * KV, h->stream));   // (the word-major pass writes every cell)
 
     stm::SolverParams sp{};
     sp.N = h->N; sp.K = K; sp.n = n; sp.V = h->V; sp.KP = h->KP; sp.zrow = (int)((int64_t)h->A * h->V);
@@ -990,17 +999,32 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     } else {
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     }
-    if (slab == (size_t)n * n) {
-        if (int rc = reduce_copies(h, h->d_sigma_part, nrep, n * n, h->d_sigma_ss)) return rc;
-        hipLaunchKernelGGL(stm::mirror_blocks_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, h->d_sigma_ss, n);
-    } else {   // the slabs of post_kernel / post_big2_kernel: summed in their tile layout, then laid out as the matrix
-        double *tiles = h->d_sigma_part + (size_t)nrep * slab;
-        if (int rc = reduce_copies(h, h->d_sigma_part, nrep, (int)slab, tiles)) return rc;
-        hipLaunchKernelGGL(stm::untile_sigma_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, (const double *)tiles, n, h->d_sigma_ss, rem_used ? 1 : 0);
+    // what follows the post kernel, in two launches (stm_epilogue.h): the nu slabs summed in their fixed order and laid out as
+    // sigma_ss, the bound, and -- for the resident EM iteration -- the regression moments and eta^T eta with their reductions
+    {
+        stm::EpiParams ep{};
+        ep.sig_part = h->d_sigma_part; ep.sig_copies = nrep; ep.sig_nn = (int)slab;
+        ep.sig_rows = nrep < 4 * RED_Y ? 1 : RED_Y;
+        ep.sig_chunk = ep.sig_rows == 1 ? nrep : (nrep + RED_Y - 1) / RED_Y;
+        ep.sig_red = h->d_red + BOUND_BLOCKS;
+        ep.n = n; ep.sig_layout = slab == (size_t)n * n ? 0 : (rem_used ? 2 : 1);
+        ep.sigma_ss = h->d_sigma_ss;
+        ep.bound = h->d_bound; ep.N = h->N; ep.bound_part = h->d_red; ep.scal = h->d_scal; ep.err = h->d_err;
+        ep.nb_sig = (int)((slab + 63) / 64) * ep.sig_rows; ep.nb_bound = BOUND_BLOCKS;
+        ep.nb_sig2 = (n * n + 255) / 256;
+        if (with_moments) {
+            const int p = h->d_X ? h->p : 0;
+            ep.X = h->d_X; ep.eta = h->d_eta; ep.p = p; ep.Lr = 1 + p + n + p * p + p * n;
+            ep.mom_part = h->d_mom; ep.mom_out = h->d_extra;
+            ep.cov_part = h->d_cov + (size_t)n * n; ep.cov_out = h->d_extra + ep.Lr;
+            ep.cov_g = (n + 63) / 64;
+            ep.nb_mom = mom_blocks((size_t)ep.Lr); ep.nb_cov = MOM_BLOCKS * ep.cov_g * ep.cov_g;
+            ep.nb_mom2 = (ep.Lr + 15) / 16; ep.nb_cov2 = (n * n + 15) / 16;
+        }
+        hipLaunchKernelGGL(stm::epilogue_a_kernel, dim3((unsigned)(ep.nb_cov + ep.nb_mom + ep.nb_sig + ep.nb_bound)), dim3(256), 0, h->stream, ep);
+        hipLaunchKernelGGL(stm::epilogue_b_kernel, dim3((unsigned)(ep.nb_cov2 + ep.nb_mom2 + ep.nb_sig2 + 1)), dim3(256), 0, h->stream, ep);
+        HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(stm::bound_partial_kernel, dim3(BOUND_BLOCKS), dim3(256), 0, h->stream, (const double *)h->d_bound, h->N, h->d_red);
-    hipLaunchKernelGGL(stm::reduce_bound_kernel, dim3(1), dim3(1024), 0, h->stream, (const double *)h->d_red, (int64_t)BOUND_BLOCKS, h->d_scal, (const int32_t *)h->d_err);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
     return STM_OK;
 }
