@@ -60,9 +60,10 @@ int stm_set_corpus(stm_handle *h, int64_t N, int32_t V, const int64_t *indptr,
                    const int32_t *indices, const double *counts, const int32_t *aspect, int32_t A);
 /* allocate K-dependent state; eta = 0, mu = 0 like stm.py:457,467.  2 <= K <= 512 (K <= 64: one topic per
  * lane and the matrix-core post kernel; 64 < K <= 112: two topics per lane in the solver, two wavefronts per document
- * in the post step; 112 < K <= 128: two topics per lane throughout; 128 < K <= 512: the general forms -- four / eight vector
- * components per lane in the solver with the slab and the BFGS matrix in HBM, stm_post_any.h for the post step: correct, not
- * tuned), K * V * 8 < 2^32 per level of beta (32-bit row offsets): STM_ERR_INVALID beyond */
+ * in the post step; 112 < K <= 128: two topics per lane in the solver, the general post step (stm_post_any.h), still without
+ * atomics; 128 < K <= 512: the general forms -- four / eight vector components per lane in the solver with the slab and the BFGS
+ * matrix in HBM, the general post step with fp64 atomics: correct, not tuned), K * V * 8 < 2^32 per level of beta (32-bit row
+ * offsets): STM_ERR_INVALID beyond */
 int stm_set_topics(stm_handle *h, int32_t K);
 int stm_put_beta(stm_handle *h, const double *beta /* [A][K][V] */);
 int stm_put_eta(stm_handle *h, const double *eta /* [N][K-1] */);
@@ -209,6 +210,11 @@ int stm_comm_init(stm_handle *h, const void *uid128, int rank, int nranks);
 /* what RCCL itself says about the handle's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): bench
  * provenance for multi-GPU lines.  nranks = 0 when the handle has no communicator. */
 int stm_comm_info(stm_handle *h, int32_t *nranks, int32_t *rank, int32_t *device);
+/* How stm_em_begin exchanges the sufficient statistics when the handle has a communicator: single = 0 (default, "split") -- two
+ * all-reduces per EM iteration, [scalars | sigma_ss | moments] in front of the host's read-back and beta_ss (K V doubles) behind it,
+ * overlapping the host's M-step algebra; single = 1 -- ONE all-reduce of the whole packed buffer (the exchange BASELINE.json's
+ * north_star names), the beta_ss pass in front of it.  Same sums either way; every rank must choose the same. */
+int stm_comm_set_exchange(stm_handle *h, int32_t single);
 /* sum over ranks, in place on the device, of the packed buffer
  * [ bound | sigma_ss | moments (as left by stm_mstep_moments) | beta_ss ];
  * the first moments_len doubles of the reduced moment region are copied to `moments` (nullable when 0).
@@ -221,6 +227,8 @@ int stm_allreduce_small(stm_handle *h, double *buf, int64_t len);
 /* HIP-event time (ms) of the kernels of the last stm_estep on the handle's
  * stream: [0] solver kernel, [1] post kernel, [2] whole E-step */
 int stm_last_kernel_ms(stm_handle *h, float *ms3);
+/* ... and of the word-major beta_ss pass alone (part of [1] above; 0 beyond 128 topics, where phi is added atomically) */
+int stm_last_pass_ms(stm_handle *h, float *ms);
 int stm_synchronize(stm_handle *h);
 
 #ifdef __cplusplus

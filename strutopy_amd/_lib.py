@@ -11,6 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STM_LIB_PATH") or os.path.join(_HERE, "libstm_hip.so")   # STM_LIB_PATH: A/B builds of the same source
+# the same sources built with -DSTM_TESTING: the debug switches (dumps, cycle counters, poisoned LDS, partial E-steps, the fault
+# injector) exist only there -- what tests/ and tools/ load when they need one (HipEstepEngine(testing=True))
+TESTING_LIB_PATH = os.environ.get("STM_TESTING_LIB_PATH") or os.path.join(_HERE, "libstm_hip_testing.so")
 
 STM_OK = 0
 STM_ERR_INVALID, STM_ERR_BETA, STM_ERR_LINALG, STM_ERR_HIP = 1, 2, 3, 4
@@ -79,18 +82,24 @@ SIGNATURES = {
     "stm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "stm_comm_init": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_int]),
     "stm_comm_info": (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "stm_comm_set_exchange": (C.c_int, [_h, C.c_int32]),
     "stm_allreduce_suffstats": (C.c_int, [_h, _dp, _dp, C.c_int64]),
     "stm_allreduce_small": (C.c_int, [_h, _dp, C.c_int64]),
     "stm_last_kernel_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
+    "stm_last_pass_ms": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "stm_synchronize": (C.c_int, [_h]),
 }
 # not part of the public header: debug dumps used by the parity tests
 _DEBUG_SIGNATURES = {
     "stm_debug_get_mats": (C.c_int, [_h, _dp, _dp, _dp]),
     "stm_debug_get_prof": (C.c_int, [_h, C.POINTER(C.c_longlong)]),
+    "stm_debug_set": (C.c_int, [_h, C.c_char_p, C.c_int]),
+    "stm_is_testing_build": (C.c_int, []),
 }
 
+_SINCE_ROUND6 = ("stm_comm_set_exchange", "stm_last_pass_ms", "stm_debug_set", "stm_is_testing_build")
 _LIB = None
+_TESTING_LIB = None
 
 
 class StmError(RuntimeError):
@@ -99,28 +108,45 @@ class StmError(RuntimeError):
         self.code = code
 
 
-def lib():
-    """Load libstm_hip.so (built by __graft_entry__.build()); raise if it is missing."""
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  strutopy_amd has no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in {**SIGNATURES, **_DEBUG_SIGNATURES}.items():
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  strutopy_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    for name, (res, args) in {**SIGNATURES, **_DEBUG_SIGNATURES}.items():
+        try:
             fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _LIB = L
+        except AttributeError:
+            # an older build loaded through STM_LIB_PATH for an A/B run (tools/bitcmp.py against last round's library) may lack the
+            # newest entry points; the library next to this file must have every one of them (tests/test_cabi.py)
+            if name in _SINCE_ROUND6 and os.environ.get("STM_LIB_PATH"):
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def lib(testing=False):
+    """Load libstm_hip.so (built by __graft_entry__.build()); raise if it is missing.  testing=True: the -DSTM_TESTING build."""
+    global _LIB, _TESTING_LIB
+    if testing:
+        if _TESTING_LIB is None:
+            _TESTING_LIB = _load(TESTING_LIB_PATH)
+            if not _TESTING_LIB.stm_is_testing_build():
+                raise ImportError(f"{TESTING_LIB_PATH} was not built with -DSTM_TESTING")
+        return _TESTING_LIB
+    if _LIB is None:
+        _LIB = _load(LIB_PATH)
     return _LIB
 
 
-def check(rc):
+def check(rc, L=None):
     """Map C-ABI error codes onto the exceptions the reference raises for the same condition."""
     if rc == STM_OK:
         return
-    msg = lib().stm_last_error().decode(errors="replace")
+    msg = (L or lib()).stm_last_error().decode(errors="replace")
     if rc in (STM_ERR_BETA, STM_ERR_PHI):
         raise AssertionError(msg)                 # stm.py:534 / stm.py:1117 are `assert`s
     if rc == STM_ERR_LINALG:

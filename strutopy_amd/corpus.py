@@ -67,7 +67,7 @@ def _packbow_module():
         return None
 
 
-def pack_bow(documents, V=None):
+def pack_bow(documents, V=None, merge_duplicates=False):
     """The corpus in any of the forms a caller may hold -> PackedCorpus, once (the reference rebuilds
     np.array(documents[i]) for every document in every EM iteration, stm.py:522-533):
 
@@ -76,9 +76,16 @@ def pack_bow(documents, V=None):
     * a PackedCorpus, or the CSR triple (indptr, indices, counts) itself: validated, no copy of already-typed arrays
     * a scipy.sparse matrix (documents x terms, what create_dtm builds, stm.py:87-119)
     * a path to a MatrixMarket file (the format of the shipped src/artifacts/wiki_data/BoW_corpus.mm)
+
+    A word id may appear once per document (gensim's doc2bow, what the reference is fed, guarantees it): a repeated id raises
+    ValueError naming the document -- a deviation from the reference, which accepts it and then counts that word's phi column once in
+    beta_ss and twice everywhere else (stm.py:588).  merge_duplicates=True sums the counts of a repeated id instead
+    (what the scipy.sparse path always does).
     """
-    if isinstance(documents, PackedCorpus):
-        return documents
+    if isinstance(documents, PackedCorpus):     # (checked once: the product's own objects carry the mark)
+        if getattr(documents, "_checked_ok", False):
+            return documents
+        return _checked(_merged(documents) if merge_duplicates else documents, V)
     if isinstance(documents, (str, os.PathLike)):
         c = read_mm(documents)
         if V is not None and c.V < V:
@@ -93,8 +100,9 @@ def pack_bow(documents, V=None):
             and isinstance(documents[1], np.ndarray) and isinstance(documents[2], np.ndarray):
         indptr, indices, counts = documents
         vmax = int(np.max(indices)) + 1 if len(indices) else 0
-        return _checked(PackedCorpus(np.ascontiguousarray(indptr, dtype=np.int64), np.ascontiguousarray(indices, dtype=np.int32),
-                                     np.ascontiguousarray(counts, dtype=np.float64), int(vmax if V is None else V)), V)
+        c = PackedCorpus(np.ascontiguousarray(indptr, dtype=np.int64), np.ascontiguousarray(indices, dtype=np.int32),
+                         np.ascontiguousarray(counts, dtype=np.float64), int(vmax if V is None else V))
+        return _checked(_merged(c) if merge_duplicates else c, V)
     N = len(documents)
     pb = _packbow_module()
     if pb is not None:
@@ -125,14 +133,48 @@ def pack_bow(documents, V=None):
         V = vmax
     elif vmax > V:
         raise IndexError(f"word id {vmax - 1} is out of range for a dictionary of length {V}")
-    return _unique_words(PackedCorpus(indptr, indices, counts, int(V)))
+    c = PackedCorpus(indptr, indices, counts, int(V))
+    return _unique_words(_merged(c) if merge_duplicates else c)
+
+
+def _merged(c):
+    """The counts of a word id that a document holds more than once, summed (the document's ids then ascend); documents without
+    a repeated id keep their order."""
+    if len(c.indices) < 2 or (c.N and np.min(np.diff(c.indptr)) < 1):
+        return c
+    doc = np.repeat(np.arange(c.N, dtype=np.int64), np.diff(c.indptr))
+    key = doc * np.int64(max(c.V, 1)) + c.indices
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    first = np.concatenate([[True], np.diff(ks) != 0])
+    if first.all():
+        return c
+    dup_docs = np.unique(doc[order][~first])
+    touched = np.isin(doc, dup_docs)
+    keep = np.flatnonzero(~touched)                         # entries of untouched documents, in place
+    o2 = order[np.isin(doc[order], dup_docs)]               # entries of the documents with repeats, sorted by (doc, id)
+    k2 = key[o2]
+    f2 = np.concatenate([[True], np.diff(k2) != 0])
+    starts = np.flatnonzero(f2)
+    m_idx, m_cnt, m_doc = c.indices[o2][starts], np.add.reduceat(c.counts[o2], starts), doc[o2][starts]
+    all_doc = np.concatenate([doc[keep], m_doc])
+    pos = np.concatenate([keep, o2[starts]])                # original positions keep the order inside untouched documents
+    fin = np.lexsort((pos, all_doc))
+    indices = np.concatenate([c.indices[keep], m_idx])[fin].astype(np.int32)
+    counts = np.concatenate([c.counts[keep], m_cnt])[fin]
+    indptr = np.zeros(c.N + 1, dtype=np.int64)
+    np.cumsum(np.bincount(all_doc, minlength=c.N), out=indptr[1:])
+    return PackedCorpus(indptr, indices, np.ascontiguousarray(counts, dtype=np.float64), c.V)
 
 
 def _unique_words(c):
     """A word id may appear once per document -- what gensim's doc2bow produces and stm_set_corpus requires (the kernels let
     no two lanes share a word's cells; the reference itself would count a repeated id's phi column once in beta_ss and twice
     everywhere else, stm.py:588).  Rejected here, with the document named; scipy.sparse input has its duplicates summed."""
+    if c.N and np.min(np.diff(c.indptr)) < 1:      # (the indexing below takes indptr - 1)
+        raise IndexError("empty document: the reference indexes doc_array[:, 0] (stm.py:523)")
     if len(c.indices) < 2:
+        c._checked_ok = True
         return c
     inner = np.ones(len(c.indices) - 1, dtype=bool)
     inner[np.asarray(c.indptr[1:-1], dtype=np.int64) - 1] = False       # pairs that straddle two documents
@@ -143,7 +185,8 @@ def _unique_words(c):
         if len(dup):
             d, w = divmod(int(key[dup[0]]), max(c.V, 1))
             raise ValueError(f"document {d} holds word id {w} more than once: merge the counts first "
-                             "(gensim's doc2bow never produces this)")
+                             "(pack_bow(..., merge_duplicates=True); gensim's doc2bow never produces this)")
+    c._checked_ok = True
     return c
 
 

@@ -15,7 +15,6 @@
 #include "stm_mstep.h"
 #include "stm_betass.h"
 #include "stm_post.h"
-#include "stm_post_big.h"
 #include "stm_post_big2.h"
 #include "stm_post_any.h"
 #include "stm_solver.h"
@@ -118,9 +117,63 @@ __global__ void copy_out_err_kernel(const double *src, double *dst, size_t cnt, 
     if (q == 0) *err_dst = *err;
 }
 
+// Every STM_* environment switch the library knows, read ONCE, in stm_create (an inherited environment cannot change kernels under
+// a live handle; INTEGRATION.md lists them).  The A/B switches select between data paths that give the same results; the debug
+// switches (dumps, cycle counters, poisoned LDS, partial E-steps, the fault injector) exist only in a build with -DSTM_TESTING
+// (strutopy_amd/libstm_hip_testing.so, what the tests and tools/ load when they need them) -- there they can also be changed on a
+// live handle with stm_debug_set.
+struct stm_switches {
+    int solver_mode = 0;             // STM_SOLVER_MODE: 0 auto (two waves per document, registers + LDS), 3 one wave, 1 LDS only, 2 global slab only
+    int solver_dma = 1;              // STM_SOLVER_DMA: K = 50 / 64 set-up through the LDS-DMA path
+    int solver_max_docs_per_cu = 16; // STM_SOLVER_MAX_DOCS_PER_CU
+    int solver_k100_direct = 1;      // STM_SOLVER_K100_DIRECT: K > 64 re-gathers beta rows per pass (0: per-document slab)
+    int solver_persist = 1;          // STM_SOLVER_PERSIST: the two-wave solver's workgroups take documents off a ticket counter
+    int slab_budget_mb = 24576;      // STM_SLAB_BUDGET_MB
+    int betass_group_kb = stm::BETASS_GROUP_BYTES >> 10;   // STM_BETASS_GROUP_KB: theta bytes per document group of the beta_ss pass
+    int betass_two = 1;              // STM_BETASS_TWO: two theta rows per load in that pass (even K)
+    int post_any = 0;                // STM_POST_ANY: every K through post_any_kernel
+    int post_big2 = 1;               // STM_POST_BIG2: 64 < K <= 112 through post_big2_kernel
+    int post_big2_waves = 2;         // STM_POST_BIG2_WAVES: 2 | 4
+    int post_rem = 1;                // STM_POST_REM
+    int post_max_wg_per_cu = 0;      // STM_POST_MAX_WG_PER_CU (0: as many as LDS and registers allow)
+    int sigma_replicas = 256;        // STM_SIGMA_REPLICAS (atomically filled nu replicas: K > 112)
+    int mom_k0 = 2, mom_k1 = 4;      // STM_MOM_K0 / STM_MOM_K1: later searches that start with a moment pass (stm_solver.h)
+    // -DSTM_TESTING only
+    int debug_prof = 0, debug_dump = 0, debug_stage = 3, debug_flags = 0, post_debug = 0, debug_fail_plan = 0;
+};
+static stm_switches read_switches() {
+    stm_switches w;
+    w.solver_mode = env_int("STM_SOLVER_MODE", w.solver_mode);
+    w.solver_dma = env_int("STM_SOLVER_DMA", w.solver_dma);
+    w.solver_max_docs_per_cu = env_int("STM_SOLVER_MAX_DOCS_PER_CU", w.solver_max_docs_per_cu);
+    w.solver_k100_direct = env_int("STM_SOLVER_K100_DIRECT", w.solver_k100_direct);
+    w.solver_persist = env_int("STM_SOLVER_PERSIST", w.solver_persist);
+    w.slab_budget_mb = env_int("STM_SLAB_BUDGET_MB", w.slab_budget_mb);
+    w.betass_group_kb = env_int("STM_BETASS_GROUP_KB", w.betass_group_kb);
+    w.betass_two = env_int("STM_BETASS_TWO", w.betass_two);
+    w.post_any = env_int("STM_POST_ANY", w.post_any);
+    w.post_big2 = env_int("STM_POST_BIG2", w.post_big2);
+    w.post_big2_waves = env_int("STM_POST_BIG2_WAVES", w.post_big2_waves);
+    w.post_rem = env_int("STM_POST_REM", w.post_rem);
+    w.post_max_wg_per_cu = env_int("STM_POST_MAX_WG_PER_CU", w.post_max_wg_per_cu);
+    w.sigma_replicas = env_int("STM_SIGMA_REPLICAS", w.sigma_replicas);
+    w.mom_k0 = env_int("STM_MOM_K0", w.mom_k0);
+    w.mom_k1 = env_int("STM_MOM_K1", w.mom_k1);
+#ifdef STM_TESTING
+    w.debug_prof = env_int("STM_DEBUG_PROF", 0);
+    w.debug_dump = env_int("STM_DEBUG_DUMP", 0);
+    w.debug_stage = env_int("STM_DEBUG_STAGE", 3);
+    w.debug_flags = env_int("STM_DEBUG_FLAGS", 0);
+    w.post_debug = env_int("STM_POST_DEBUG", 0);
+    w.debug_fail_plan = env_int("STM_DEBUG_FAIL_PLAN", 0);
+#endif
+    return w;
+}
+
 }  // namespace
 
 struct stm_handle {
+    stm_switches sw;
     int device = 0;
     hipStream_t stream = nullptr;
     int cu = 0;
@@ -166,7 +219,9 @@ struct stm_handle {
     size_t red_len = 0;
     bool dma = false;            // two-wave solver with LDS-staged row gather (K == KREG = 50 or 64)
     bool direct = false;         // K > 64: rows re-gathered from betaT per pass instead of a per-document slab
-    bool any = false;            // K > 128 (or STM_POST_ANY=1): the general post kernel (stm_post_any.h), phi / nu by atomics
+    bool any = false;            // K > 112 (or STM_POST_ANY=1): the general post kernel (stm_post_any.h)
+    bool wm = false;             // phi through r_dw + the word-major beta_ss pass and nu in per-workgroup slabs (run-to-run identical): every K <= 128;
+                                 // beyond, post_any_kernel adds both with fp64 atomics
     bool big2 = false;           // 64 < K <= 112: the two-waves-per-document post kernel (stm_post_big2.h) + the word-major beta_ss pass
     // optional dumps
     double *d_phi = nullptr;
@@ -182,7 +237,8 @@ struct stm_handle {
     int rank = 0, nranks = 1;
     double *d_pack = nullptr, *d_extra = nullptr, *d_small = nullptr;
     size_t extra_cap = 0, small_len = 0;
-    double *d_ascratch = nullptr; size_t ascratch_len = 0;   // post_big_kernel's per-workgroup A
+    double *d_ascratch = nullptr; size_t ascratch_len = 0;   // post_any_kernel's per-workgroup A, L, b
+    bool exchange_single = false;   // stm_comm_set_exchange: ONE all-reduce of the whole packed buffer per EM iteration instead of two
     size_t pack_len = 0;
     void *spectral = nullptr;   // spectral-initialisation workspace (stm_spectral_api.inc)
     // timing
@@ -279,6 +335,7 @@ static SolverFn solver_fn(int kreg, bool global_slab, int nw = 1, int vpl = 1, b
 static int slab_row(int K) { return ((std::max(K, 2) - 2 + 3) / 4) * 4 + 2; }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr int64_t GENERAL_DOCS_PER_LAUNCH = 4096;   // documents per launch of the solver's general forms (K > 128)
 constexpr int SOLVER_TICKETS = 63;     // ticket counters of the persistent solver launches of one E-step (behind the error flag in d_err)
 constexpr size_t LDS_STATIC = 4096;   // static LDS of the solver kernel (se, sv, sw, mailbox, scalar state) when the runtime cannot be asked
 
@@ -287,7 +344,7 @@ static int plan_solver(stm_handle *h) {
     const int K = h->K;
     // STM_SOLVER_MODE: 0 auto (two waves per document, registers + LDS), 3 one wave (registers + LDS),
     // 1 one wave, LDS only, 2 one wave, global slab only (v1 data path)
-    const int mode = env_int("STM_SOLVER_MODE", 0);
+    const int mode = h->sw.solver_mode;
     h->kreg = 0;
     h->nw = 1;
     if (mode == 0 || mode == 3) h->kreg = K <= 16 ? 16 : K <= 32 ? 32 : K <= 50 ? 50 : 64;
@@ -296,14 +353,14 @@ static int plan_solver(stm_handle *h) {
     if (h->vpl >= 2) { h->kreg = 0; h->nw = 1; }   // two (four, eight) vector components per lane: beta_d in LDS / HBM only
     // rows through the LDS-DMA path: needs K == KREG (packed rows of K doubles are the slab's rows) and 32-bit row offsets
     h->dma = h->nw == 2 && K == h->kreg && (K == 50 || K == 64) && slab_row(K) == 2 * ((K / 2) | 1) &&
-             ((size_t)h->A * h->V * K + 64) * sizeof(double) < ((size_t)1 << 32) && env_int("STM_SOLVER_DMA", 1) != 0;
+             ((size_t)h->A * h->V * K + 64) * sizeof(double) < ((size_t)1 << 32) && h->sw.solver_dma != 0;
     const int vreg = h->kreg > 0 ? 64 * h->nw : 0;
-    const int cmax = std::max(1, env_int("STM_SOLVER_MAX_DOCS_PER_CU", 16));
+    const int cmax = std::max(1, h->sw.solver_max_docs_per_cu);
     const int KP = slab_row(h->kreg > 0 ? std::max(h->kreg, K) : K);
     h->KP = KP;
     const size_t h_lds = h->nw == 2 ? ((size_t)h->n * h->n + (h->dma ? (size_t)stm::solver_dma_stage_extra(h->kreg, h->n) : 0)) * sizeof(double) : 0;  // BFGS matrix in LDS (two-wave form) + what the DMA staging needs beyond it
     // K > 64 (STM_SOLVER_K100 = "direct" unless set to 0): no copy of beta_d, one 16-word LDS tile re-gathered from betaT per pass
-    h->direct = h->vpl == 2 && mode == 0 && env_int("STM_SOLVER_K100_DIRECT", 1) != 0;
+    h->direct = h->vpl == 2 && mode == 0 && h->sw.solver_k100_direct != 0;
     auto lds_of = [&](int nd) {
         if (h->direct) return (size_t)16 * KP * sizeof(double) + (size_t)nd * (2 * sizeof(double) + sizeof(int32_t)) + 16;
         return (size_t)(KP + 2) * (size_t)std::max(0, nd - vreg) * sizeof(double) + h_lds;
@@ -328,7 +385,7 @@ static int plan_solver(stm_handle *h) {
     h->groups.clear();
     size_t max_dyn = 0, glob_len = 0;
     const int64_t N = h->N;
-    const size_t budget = (size_t)env_int("STM_SLAB_BUDGET_MB", 24576) << 20;
+    const size_t budget = (size_t)h->sw.slab_budget_mb << 20;
     for (int64_t i = 0; i < N;) {
         const int nd = h->h_len_sorted[(size_t)i];
         const int c = per_cu(nd);
@@ -338,7 +395,8 @@ static int plan_solver(stm_handle *h) {
         if (c == 0) {
             g.ld = (nd + 63) / 64 * 64;
             const size_t per_doc = (size_t)(KP + 2) * g.ld;
-            const size_t docs = std::min<size_t>((size_t)(j - i), std::max<size_t>(1, budget / (per_doc * sizeof(double))));
+            size_t docs = std::min<size_t>((size_t)(j - i), std::max<size_t>(1, budget / (per_doc * sizeof(double))));
+            if (h->vpl > 2) docs = std::min<size_t>(docs, GENERAL_DOCS_PER_LAUNCH);   // (K > 128: see stm_set_topics)
             glob_len = std::max(glob_len, docs * per_doc);
         } else {
             g.ld = std::max(0, nd - vreg);
@@ -371,7 +429,7 @@ static int plan_solver(stm_handle *h) {
 static int build_word_major(stm_handle *h) {
     const int64_t N = h->N, nnz = h->nnz;
     const size_t R = (size_t)h->A * (size_t)h->V;
-    const int64_t gdocs = std::max<int64_t>(1, (int64_t)env_int("STM_BETASS_GROUP_KB", stm::BETASS_GROUP_BYTES >> 10) * 1024 / ((int64_t)h->K * 8));
+    const int64_t gdocs = std::max<int64_t>(1, (int64_t)h->sw.betass_group_kb * 1024 / ((int64_t)h->K * 8));
     int64_t G = std::max<int64_t>(1, (N + gdocs - 1) / gdocs);
     G = std::min<int64_t>(G, 64);
     G = std::min<int64_t>(G, std::max<int64_t>(1, ((int64_t)256 << 20) / (int64_t)std::max<size_t>(R * (size_t)h->K, 1)));   // <= 2 GB of partial sums
@@ -430,6 +488,7 @@ int stm_create(stm_handle **out, int device_ordinal) {
         return fail(STM_ERR_NO_DEVICE, "no HIP device available (the E-step has no CPU fallback)");
     if (device_ordinal < 0 || device_ordinal >= cnt) return fail(STM_ERR_INVALID, "bad device ordinal");
     stm_handle *h = new stm_handle();
+    h->sw = read_switches();
     h->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess) { delete h; return fail(STM_ERR_HIP, "hipSetDevice failed"); }
     hipDeviceProp_t pr;
@@ -603,15 +662,19 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     if (int rc = dalloc(&h->d_pd, N)) return rc;
     if (int rc = dalloc(&h->d_counters, 8)) return rc;
     if (int rc = dalloc(&h->d_err, 1 + SOLVER_TICKETS)) return rc;   // [0] the error flag, [1..] the ticket counters of the persistent solver launches
-    h->any = K > 128 || env_int("STM_POST_ANY", 0) != 0;
-    h->big2 = !h->any && stm::post2_serves(K) && env_int("STM_POST_BIG2", 1) != 0;
-    if (!h->any && (K <= stm::PT || h->big2)) if (int rc = build_word_major(h)) return rc;   // stm_betass.h (post_big_kernel adds phi atomically)
+    h->big2 = h->sw.post_any == 0 && stm::post2_serves(K) && h->sw.post_big2 != 0;
+    h->any = (K > stm::PT && !h->big2) || h->sw.post_any != 0;   // (112 < K <= 128 ran a one-wave matrix-core kernel of its own until round 5: occupancy 1, scratch, atomics)
+    h->wm = K <= 128;
+    if (h->wm) if (int rc = build_word_major(h)) return rc;   // stm_betass.h
     // one block (one wave) per document.  The solver keeps beta_d on chip (64 words in registers,
     // the rest in LDS); launches are cut so every launch has one LDS size / occupancy class.
     if (int rc = plan_solver(h)) return rc;
-    const size_t budget = (size_t)env_int("STM_SLAB_BUDGET_MB", 24576) << 20;
+    const size_t budget = (size_t)h->sw.slab_budget_mb << 20;
     h->chunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(h->N, 1), (int64_t)(budget / std::max<size_t>(n * n * sizeof(double), 8))));
-    h->nrep = env_int("STM_SIGMA_REPLICAS", 256);
+    // K > 128 (the general forms): every document of a launch holds its BFGS matrix (2 MB at K = 512) and its copy of beta_d in HBM -- a
+    // bounded number of workgroups per launch (sixteen per CU) instead of whatever the 24 GB budget allows; more launches, not more memory
+    if (h->vpl > 2) h->chunk = (int)std::min<int64_t>(h->chunk, GENERAL_DOCS_PER_LAUNCH);
+    h->nrep = h->sw.sigma_replicas;
     {   // documents that keep their BFGS matrix in the global slab: all of them for the one-wave forms,
         // only the too-long-for-LDS groups for the two-wave form
         int64_t need = 0;
@@ -628,11 +691,11 @@ int stm_set_topics(stm_handle *h, int32_t K) {
     h->beta_set = false;
     dfree(h->d_hess); dfree(h->d_chol); dfree(h->d_nu);
     dfree(h->d_prof);
-    if (env_int("STM_DEBUG_PROF", 0)) {
+    if (h->sw.debug_prof) {
         if (int rc = dalloc(&h->d_prof, N * stm::PROF_SLOTS)) return rc;
         HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * N * stm::PROF_SLOTS));
     }
-    if (env_int("STM_DEBUG_DUMP", 0)) {
+    if (h->sw.debug_dump) {
         if (int rc = dalloc(&h->d_hess, N * n * n)) return rc;
         if (int rc = dalloc(&h->d_chol, N * n * n)) return rc;
         if (int rc = dalloc(&h->d_nu, N * n * n)) return rc;
@@ -759,7 +822,7 @@ static int bss_enqueue(stm_handle *h) {
     h->bss_pair ^= 1; h->bss_pair_used = true;
     HIP_TRY(hipEventRecord(h->ev_b[2 * h->bss_pair], h->stream));
     // even K: two rows per load instruction (needs 16-byte aligned rows and N K 8 < 4 GiB for its 32-bit offsets)
-    const bool two = (K % 2 == 0) && (size_t)h->N * K * 8 < ((size_t)1 << 32) && env_int("STM_BETASS_TWO", 1) != 0;
+    const bool two = (K % 2 == 0) && (size_t)h->N * K * 8 < ((size_t)1 << 32) && h->sw.betass_two != 0;
     if (two && K <= 64) hipLaunchKernelGGL((stm::beta_ss_part2_kernel<8, stm::BETASS_ROWS, 2>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
     else if (two) hipLaunchKernelGGL((stm::beta_ss_part2_kernel<8, stm::BETASS_ROWS, 1>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
     else if (K <= 64) hipLaunchKernelGGL((stm::beta_ss_part_kernel<8, stm::BETASS_ROWS, 1>), dim3((unsigned)(bpg * h->G)), dim3(256), 0, h->stream, bp);
@@ -786,7 +849,7 @@ static void bss_time(stm_handle *h) {
 using PostFn = void (*)(stm::PostParams);
 struct EstepPlan {
     int dbg_stage = 3, post_debug = 0;
-    bool run_post = false, rem_used = false, big = false;
+    bool run_post = false, rem_used = false;
     PostFn pfn = nullptr;
     unsigned wg_threads = 64;
     size_t lds = 0, slab = 0;
@@ -795,8 +858,10 @@ struct EstepPlan {
 };
 static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
     const int n = h->n, K = h->K;
-    const int dbg_stage = env_int("STM_DEBUG_STAGE", 3);  // 0: no kernels, 1: solver only, 3: all
-    if (env_int("STM_DEBUG_FAIL_PLAN", 0)) return fail(STM_ERR_HIP, "STM_DEBUG_FAIL_PLAN: simulated allocation failure in the E-step's plan");   // (tests)
+    const int dbg_stage = h->sw.debug_stage;  // 0: no kernels, 1: solver only, 3: all
+#ifdef STM_TESTING
+    if (h->sw.debug_fail_plan) return fail(STM_ERR_HIP, "STM_DEBUG_FAIL_PLAN: simulated allocation failure in the E-step's plan");   // (the fault injector of tests/test_gpu_round2.py; not in the product build)
+#endif
     if (em_stage) if (int rc = ensure_pinned(h, &h->stage_sig, &h->stage_sig_cap, sizeof(double) * (size_t)n * n)) return rc;
     // last document's phi is what the reference leaves in self.phi (stm.py:1116)
     h->phi_doc = h->N - 1;
@@ -805,19 +870,18 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
         if (int rc = ensure(&h->d_phi, &h->phi_len, (size_t)K * nd)) return rc;
     }
     const bool run_post = (dbg_stage & 2) && h->N > 0;
-    const int post_debug = env_int("STM_POST_DEBUG", 0);
+    const int post_debug = h->sw.post_debug;
     PostFn pfn = nullptr;
     unsigned wg_threads = 64;
     size_t lds = 0, slab = (size_t)n * n;
     int64_t grid = 0;
     int nrep = h->nrep;
     bool rem_used = false;   // K <= 64 post kernel instantiated with REM = 1 (decides the layout of its nu slabs)
-    bool big = false;
     if (run_post) {
         // persistent workgroups: as many as the LDS / register budget keeps resident.  The matrix is n x n (n = K - 1):
         // 16 x 16 MFMA blocks, and when n is one past a multiple of 16 (K = 50: 49 = 3 * 16 + 1) the last row / column
         // of b b^T rides on the VALU instead of a padded block (post_kernel)
-        const bool rem = n > 16 && n % 16 == 1 && env_int("STM_POST_REM", 1);
+        const bool rem = n > 16 && n % 16 == 1 && h->sw.post_rem;
         const int nb = rem ? n / 16 : (n + 15) / 16;
         const bool dbg = h->d_nu != nullptr || h->d_prof != nullptr || post_debug != 0;
         PostFn pf;
@@ -832,14 +896,11 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
         }
         const bool big2 = h->big2;                  // two waves per document (stm_post_big2.h)
         const bool any = h->any;                    // any K: one workgroup per document, everything in HBM scratch (stm_post_any.h)
-        big = K > stm::PT && !big2 && !any;         // one wave per document, two topics per lane (stm_post_big.h): 112 < K <= 128
         rem_used = rem && K <= stm::PT && !any;
         const int nbb = (n + 15) / 16;
-        const PostFn pfb = nbb <= 4 ? stm::post_big_kernel<4> : nbb == 5 ? stm::post_big_kernel<5> : nbb == 6 ? stm::post_big_kernel<6>
-                           : nbb == 7 ? stm::post_big_kernel<7> : stm::post_big_kernel<8>;
         PostFn pf2 = nullptr;
         const int pc2 = stm::post2_pc(K);
-        const int nwv2 = env_int("STM_POST_BIG2_WAVES", 2) == 4 ? 4 : 2;   // waves per document (stm_post_big2.h)
+        const int nwv2 = h->sw.post_big2_waves == 4 ? 4 : 2;   // waves per document (stm_post_big2.h)
         if (big2) {
 #define STM_PB2(NBV, PCV) (nwv2 == 4 ? (dbg ? stm::post_big2_kernel<NBV, PCV, true, 4> : stm::post_big2_kernel<NBV, PCV, false, 4>) \
                                      : (dbg ? stm::post_big2_kernel<NBV, PCV, true, 2> : stm::post_big2_kernel<NBV, PCV, false, 2>))
@@ -847,31 +908,31 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
             else pf2 = nbb <= 5 ? STM_PB2(5, 56) : nbb == 6 ? STM_PB2(6, 56) : STM_PB2(7, 56);
 #undef STM_PB2
         }
-        pfn = any ? (PostFn)stm::post_any_kernel : big2 ? pf2 : big ? pfb : pf;
+        pfn = any ? (h->wm ? (PostFn)stm::post_any_kernel<true> : (PostFn)stm::post_any_kernel<false>) : big2 ? pf2 : pf;
         wg_threads = any ? (unsigned)stm::ANY_BS : big2 ? 64u * (unsigned)nwv2 : 64u;
-        lds = (any ? stm::post_any_lds_doubles(K) : big2 ? (size_t)stm::post2_lds_map(K, pc2).total : big ? stm::post_big_lds_doubles(n) : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
+        lds = (any ? stm::post_any_lds_doubles(K) : big2 ? (size_t)stm::post2_lds_map(K, pc2).total : (size_t)stm::post_lds_map(K, nb).total) * sizeof(double);
         if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)pfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)pfn, (int)wg_threads, lds));
-        per_cu = std::max(1, std::min(per_cu, env_int("STM_POST_MAX_WG_PER_CU", any ? 4 : 16)));
+        per_cu = std::max(1, std::min(per_cu, h->sw.post_max_wg_per_cu > 0 ? h->sw.post_max_wg_per_cu : (any ? 4 : 16)));
         grid = std::min<int64_t>(h->N, (int64_t)per_cu * std::max(h->cu, 1));
-        if (big)    // A (upper triangle) of the document a workgroup is on: HBM scratch, L2-resident
-            if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * n * n)) return rc;
+        if (any)    // ... its per-workgroup HBM scratch (A, L, b: 4 MB + N_d K doubles at K = 512) stays below 4 GB
+            grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(((size_t)4 << 30) / (stm::post_any_scratch(K, h->nd_max) * sizeof(double)))));
         if (any) {  // A, L, b and sqrt(c) of the document a workgroup is on (sized for the longest document)
             if (int rc = ensure(&h->d_ascratch, &h->ascratch_len, (size_t)grid * stm::post_any_scratch(K, h->nd_max))) return rc;
         }
-        // nu is summed per workgroup in a slab of its own (post_kernel, post_big2_kernel: plain read-modify-write, nrep = grid) or
-        // atomically into nrep replicas (post_big_kernel); reduce_sigma_kernel adds them in a fixed order
-        nrep = (big || any) ? h->nrep : (int)grid;
+        // nu is summed per workgroup in a slab of its own (plain read-modify-write, nrep = grid) or, beyond 128 topics, atomically into
+        // nrep replicas (post_any_kernel<false>); the epilogue adds them in a fixed order
+        nrep = h->wm ? (int)grid : h->nrep;
         const int nbc = (n + 15) / 16;
         // accumulator-tile layout; with REM (post_kernel) the last column has a slot of its own instead of a block column of tiles
-        slab = (big || any) ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
+        slab = any ? (size_t)n * n : (rem_used ? (size_t)((nbc - 1) * nbc / 2 + 1) * 256 : (size_t)(nbc * (nbc + 1) / 2) * 256);
         if (int rc = ensure(&h->d_sigma_part, &h->sigma_part_len, (size_t)nrep * slab + slab)) return rc;   // + one slab: the reduced tiles
     }
     // the first stage of the two-stage reductions + the bound's block sums (reduce_copies grows it otherwise)
     if (int rc = ensure(&h->d_red, &h->red_len, (size_t)RED_Y * std::max(slab, (size_t)n * n) + BOUND_BLOCKS)) return rc;
 
-    pl.dbg_stage = dbg_stage; pl.post_debug = post_debug; pl.run_post = run_post; pl.rem_used = rem_used; pl.big = big;
+    pl.dbg_stage = dbg_stage; pl.post_debug = post_debug; pl.run_post = run_post; pl.rem_used = rem_used;
     pl.pfn = pfn; pl.wg_threads = wg_threads; pl.lds = lds; pl.slab = slab; pl.grid = grid; pl.nrep = nrep;
     return STM_OK;
 }
@@ -893,7 +954,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
         sig_bound = std::max(sig_bound, r);
     }
     const size_t KV = (size_t)h->A * K * h->V;
-    const bool wm = !h->any && (K <= stm::PT || h->big2);    // phi through r_dw + the word-major pass (post_big_kernel adds it atomically)
+    const bool wm = h->wm;    // phi through r_dw + the word-major pass (beyond 128 topics post_any_kernel adds it atomically)
     // ---- (A) the plan (estep_plan: every fallible host-side step), unless the caller made it already
     EstepPlan pl_own;
     if (!ready) { if (int rc = estep_plan(h, em_stage, pl_own)) return rc; }
@@ -935,8 +996,8 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     sp.slab_beta = h->d_slab_beta; sp.slab_H = h->d_slab_H;
     sp.order = h->d_order; sp.tick = h->d_tick; sp.status = h->d_status; sp.nit = h->d_nit; sp.nfev = h->d_nfev; sp.njev = h->d_njev;
     sp.err_flag = h->d_err;
-    sp.debug_flags = env_int("STM_DEBUG_FLAGS", 0);
-    sp.mom_k0 = env_int("STM_MOM_K0", 2); sp.mom_k1 = env_int("STM_MOM_K1", 4);   // later searches that start with a moment pass (stm_solver.h)
+    sp.debug_flags = h->sw.debug_flags;
+    sp.mom_k0 = h->sw.mom_k0; sp.mom_k1 = h->sw.mom_k1;   // later searches that start with a moment pass (stm_solver.h)
     sp.prof = h->d_prof;
 
     stm::PostParams pp{};
@@ -950,7 +1011,6 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
     pp.phi_doc = h->phi_doc; pp.phi_out = h->d_phi;
     pp.debug_flags = post_debug;
     pp.prof = h->d_prof;
-    pp.MLD = stm::post_big_mld(n);   // (post_big_kernel only)
     pp.lds_doubles = (int)(lds / sizeof(double));
     pp.a_scratch = h->d_ascratch;
     pp.nd_max = h->nd_max;
@@ -959,7 +1019,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
 
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     int n_launch = 0;
-    const bool solver_persist = env_int("STM_SOLVER_PERSIST", 1) != 0;
+    const bool solver_persist = h->sw.solver_persist != 0;
     if (dbg_stage & 1)
         for (const auto &gr : h->groups) {
             const SolverFn fn = gr.global ? solver_fn(0, true, 1, h->vpl) : solver_fn(h->kreg, false, h->nw, h->vpl, h->direct, h->dma);
@@ -1021,7 +1081,7 @@ static int estep_enqueue(stm_handle *h, const double *siginv, double sigmaentrop
             ep.nb_mom = mom_blocks((size_t)ep.Lr); ep.nb_cov = MOM_BLOCKS * ep.cov_g * ep.cov_g;
             ep.nb_mom2 = (ep.Lr + 15) / 16; ep.nb_cov2 = (n * n + 15) / 16;
         }
-        hipLaunchKernelGGL(stm::epilogue_a_kernel, dim3((unsigned)(ep.nb_cov + ep.nb_mom + ep.nb_sig + ep.nb_bound)), dim3(256), 0, h->stream, ep);
+        hipLaunchKernelGGL(n <= 64 ? stm::epilogue_a_kernel<true> : stm::epilogue_a_kernel<false>, dim3((unsigned)(ep.nb_cov + ep.nb_mom + ep.nb_sig + ep.nb_bound)), dim3(256), 0, h->stream, ep);
         hipLaunchKernelGGL(stm::epilogue_b_kernel, dim3((unsigned)(ep.nb_cov2 + ep.nb_mom2 + ep.nb_sig2 + 1)), dim3(256), 0, h->stream, ep);
         HIP_TRY(hipGetLastError());
     }
@@ -1062,9 +1122,35 @@ int stm_get_phi(stm_handle *h, int64_t doc, double *phi) {
     return get_vec(h, phi, h->d_phi, (size_t)h->K * nd);
 }
 
+// Tests and tools: a debug switch on a live handle (name = the environment variable's).  A product build has none.
+int stm_debug_set(stm_handle *h, const char *name, int value) {
+    if (!h || !name) return fail(STM_ERR_INVALID, "stm_debug_set: null argument");
+#ifdef STM_TESTING
+    const std::string k(name);
+    if (k == "STM_DEBUG_PROF") h->sw.debug_prof = value;            // (both: before stm_set_topics)
+    else if (k == "STM_DEBUG_DUMP") h->sw.debug_dump = value;
+    else if (k == "STM_DEBUG_STAGE") h->sw.debug_stage = value;
+    else if (k == "STM_DEBUG_FLAGS") h->sw.debug_flags = value;
+    else if (k == "STM_POST_DEBUG") h->sw.post_debug = value;
+    else if (k == "STM_DEBUG_FAIL_PLAN") h->sw.debug_fail_plan = value;
+    else return fail(STM_ERR_INVALID, "stm_debug_set: unknown switch " + k);
+    return STM_OK;
+#else
+    (void)value;
+    return fail(STM_ERR_INVALID, std::string("stm_debug_set(") + name + "): this library was built without -DSTM_TESTING (debug switches live in libstm_hip_testing.so)");
+#endif
+}
+int stm_is_testing_build(void) {
+#ifdef STM_TESTING
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int stm_debug_get_prof(stm_handle *h, long long *out) {
     NEED_MODEL(h);
-    if (!h->d_prof) return fail(STM_ERR_INVALID, "set STM_DEBUG_PROF=1 before stm_set_topics");
+    if (!h->d_prof) return fail(STM_ERR_INVALID, "cycle counters are off (a -DSTM_TESTING build with STM_DEBUG_PROF=1 / stm_debug_set before stm_set_topics)");
     HIP_TRY(hipMemcpy(out, h->d_prof, sizeof(long long) * (size_t)h->N * stm::PROF_SLOTS, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(h->d_prof, 0, sizeof(long long) * (size_t)h->N * stm::PROF_SLOTS));
     return STM_OK;
@@ -1072,7 +1158,7 @@ int stm_debug_get_prof(stm_handle *h, long long *out) {
 
 int stm_debug_get_mats(stm_handle *h, double *hess, double *chol, double *nu) {
     NEED_MODEL(h);
-    if (!h->d_hess) return fail(STM_ERR_INVALID, "set STM_DEBUG_DUMP=1 before stm_set_topics");
+    if (!h->d_hess) return fail(STM_ERR_INVALID, "matrix dumps are off (a -DSTM_TESTING build with STM_DEBUG_DUMP=1 / stm_debug_set before stm_set_topics)");
     const size_t cnt = (size_t)h->N * h->n * h->n;
     if (hess) if (int rc = get_vec(h, hess, h->d_hess, cnt)) return rc;
     if (chol) if (int rc = get_vec(h, chol, h->d_chol, cnt)) return rc;
@@ -1086,8 +1172,14 @@ int stm_last_kernel_ms(stm_handle *h, float *ms3) {
     // iteration) runs behind the E-step's last event and may still be in flight: the last COMPLETED pass stands in for it
     // (its time does not vary from one iteration to the next), 0 before any has completed.
     bss_time(h);
-    const float pass = (!h->any && (h->K <= 64 || h->big2)) ? h->ms_bss : 0.0f;
+    const float pass = h->wm ? h->ms_bss : 0.0f;
     ms3[0] = h->ms[0]; ms3[1] = h->ms[1] + pass; ms3[2] = h->ms[2] + (h->last_deferred ? pass : 0.0f);
+    return STM_OK;
+}
+int stm_last_pass_ms(stm_handle *h, float *ms) {
+    if (!h || !ms) return fail(STM_ERR_INVALID, "null argument");
+    bss_time(h);
+    *ms = h->wm ? h->ms_bss : 0.0f;
     return STM_OK;
 }
 int stm_synchronize(stm_handle *h) {

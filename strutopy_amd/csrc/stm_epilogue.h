@@ -143,11 +143,15 @@ __device__ __forceinline__ void moments_block(const double *X, const double *eta
 }
 
 constexpr int COV_TD = 32;   // documents per LDS tile of the covariance block
+// covariance_kernel's block (bx, by, bz).  ONE: n <= 64 -- the row-side and the column-side components of a tile are the same 64, held
+// once (half the loads, half the LDS: nine blocks per CU instead of four); the sums are the same, term for term.
+template <bool ONE>
 __device__ __forceinline__ void covariance_block(const double *eta, const double *mu, int64_t N, int n, double *part, int bx, int by, int bz, int gx,
-                                                 double (*diff)[130] /* [COV_TD][130] */) {
+                                                 double *tile /* [COV_TD][ONE ? 66 : 130] */) {
+    constexpr int W = ONE ? 64 : 128, LDW = W + 2, PER = COV_TD * W / 256;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int jc = 4 * tx + 64 * by, ib = 4 * ty + 64 * bz;
-    const int ia = 4 * ty, ja = 64 + 4 * tx;
+    const int ia = 4 * ty, ja = (ONE ? 0 : 64) + 4 * tx;
     double acc[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -159,25 +163,25 @@ __device__ __forceinline__ void covariance_block(const double *eta, const double
     for (int64_t base = d0; base < d1; base += COV_TD) {
         const int cnt = (int)((d1 - base) < COV_TD ? (d1 - base) : COV_TD);
         {
-            double v[COV_TD * 128 / 256];
+            double v[PER];
 #pragma unroll
-            for (int it = 0; it < COV_TD * 128 / 256; ++it) {
-                const int q = threadIdx.x + 256 * it, dd = q >> 7, c = q & 127;
-                const int i = (c < 64 ? 64 * bz : 64 * by - 64) + c;
+            for (int it = 0; it < PER; ++it) {
+                const int q = threadIdx.x + 256 * it, dd = q / W, c = q & (W - 1);
+                const int i = ONE ? c : (c < 64 ? 64 * bz : 64 * by - 64) + c;
                 const bool in = dd < cnt && i < n;
                 const int64_t at = in ? (base + dd) * n + i : 0;
                 const double e = eta[at], m = mu ? mu[at] : 0.0;
                 v[it] = in ? (mu ? e - m : e) : 0.0;
             }
 #pragma unroll
-            for (int it = 0; it < COV_TD * 128 / 256; ++it) {
+            for (int it = 0; it < PER; ++it) {
                 const int q = threadIdx.x + 256 * it;
-                diff[q >> 7][q & 127] = v[it];
+                tile[(q / W) * LDW + (q & (W - 1))] = v[it];
             }
         }
         __syncthreads();
         for (int dd = 0; dd < cnt; ++dd) {
-            const double2 *row = reinterpret_cast<const double2 *>(&diff[dd][0]);
+            const double2 *row = reinterpret_cast<const double2 *>(tile + dd * LDW);
             const double2 a01 = row[ia >> 1], a23 = row[(ia >> 1) + 1], b01 = row[ja >> 1], b23 = row[(ja >> 1) + 1];
             const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
 #pragma unroll
@@ -234,12 +238,13 @@ __device__ __forceinline__ void bound_partial_block(const double *bound, int64_t
 }
 
 // ---- stage A: everything that reads what the post kernel left and nothing else -------------------------------------------------------
+template <bool ONE>   // ONE: n <= 64 (covariance_block)
 __global__ __launch_bounds__(256) void epilogue_a_kernel(EpiParams ep) {
-    __shared__ __attribute__((aligned(16))) double smem[COV_TD * 130];
+    __shared__ __attribute__((aligned(16))) double smem[COV_TD * (ONE ? 66 : 130)];
     int id = blockIdx.x;
     if (id < ep.nb_cov) {       // the longest blocks first
         const int bx = id % EPI_COV_BLOCKS, r = id / EPI_COV_BLOCKS;
-        covariance_block(ep.eta, nullptr, ep.N, ep.n, ep.cov_part, bx, r % ep.cov_g, r / ep.cov_g, EPI_COV_BLOCKS, reinterpret_cast<double (*)[130]>(smem));
+        covariance_block<ONE>(ep.eta, nullptr, ep.N, ep.n, ep.cov_part, bx, r % ep.cov_g, r / ep.cov_g, EPI_COV_BLOCKS, smem);
         return;
     }
     id -= ep.nb_cov;
@@ -369,13 +374,20 @@ __global__ __launch_bounds__(256) void mstep_tail_a_kernel(TailParams tp) {
     }
     const int64_t tot = tp.N * tp.n;
     const int n = tp.n, p = tp.p;
-    for (int64_t q = (int64_t)id * 256 + threadIdx.x; q < tot; q += (int64_t)tp.nb_mu * 256) {
-        const int64_t d = q / n;
-        const int i = (int)(q % n);
-        if (!tp.X) { tp.mu[q] = coef[i]; continue; }
+    auto one = [&](int64_t q, int64_t d, int i) __attribute__((always_inline)) {
+        if (!tp.X) { tp.mu[q] = coef[i]; return; }
         double t = 0.0;
         for (int a = 0; a < p; ++a) t += tp.X[d * p + a] * coef[(size_t)i * p + a];
         tp.mu[q] = t;
+    };
+    if (tot < ((int64_t)1 << 32)) {   // (a 64-bit division per element is most of the kernel otherwise)
+        const unsigned un = (unsigned)n, step = (unsigned)tp.nb_mu * 256u;
+        for (uint64_t q = (uint64_t)id * 256 + threadIdx.x; q < (uint64_t)tot; q += step) {
+            const unsigned d = (unsigned)q / un;
+            one((int64_t)q, d, (int)((unsigned)q - d * un));
+        }
+    } else {
+        for (int64_t q = (int64_t)id * 256 + threadIdx.x; q < tot; q += (int64_t)tp.nb_mu * 256) one(q, q / n, (int)(q % n));
     }
 }
 
@@ -395,10 +407,18 @@ __global__ __launch_bounds__(256) void mstep_tail_b_kernel(TailParams tp) {
             if ((int)threadIdx.x < kc) rs[k0 + threadIdx.x] = reduce_row_value(tp.rs_part, (size_t)K, k0 + (int)threadIdx.x, 0, nb);
         } else {
             const int chunk = (nb + EPI_RED_Y - 1) / EPI_RED_Y;
-            for (int e = threadIdx.x; e < EPI_RED_Y * kc; e += 256) {
+            double val[EPI_RED_Y * 64 / 256];   // (every row sum's loads in flight at once: the rounds are memory round trips)
+#pragma unroll
+            for (int u = 0; u < EPI_RED_Y * 64 / 256; ++u) {
+                const int e = threadIdx.x + 256 * u;
                 const int y = e / kc, kk = e % kc;
                 const int lo = y * chunk, hi = lo + chunk < nb ? lo + chunk : nb;
-                s1[y * 64 + kk] = reduce_row_value(tp.rs_part, (size_t)K, k0 + kk, lo, hi);
+                val[u] = e < EPI_RED_Y * kc ? reduce_row_value(tp.rs_part, (size_t)K, k0 + kk, lo, hi) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < EPI_RED_Y * 64 / 256; ++u) {
+                const int e = threadIdx.x + 256 * u;
+                if (e < EPI_RED_Y * kc) s1[(e / kc) * 64 + e % kc] = val[u];
             }
             __syncthreads();
             if ((int)threadIdx.x < kc) rs[k0 + threadIdx.x] = reduce_row_value(s1, 64, (int)threadIdx.x, 0, EPI_RED_Y);

@@ -1,4 +1,4 @@
-// stm_post_any.h -- the post-solve step for ANY number of topics (the product path for K > 128; STM_POST_ANY=1 selects it for every K
+// stm_post_any.h -- the post-solve step for ANY number of topics (the product path for K > 112; STM_POST_ANY=1 selects it for every K
 // as a second implementation the tests hold against the matrix-core kernels).
 //
 // Same arithmetic as the other post kernels (reference src/modules/stm.py:547-588: theta, hessian + make_pd ladder,
@@ -7,8 +7,10 @@
 // per-workgroup HBM scratch -- A (the Hessian with its fixes, n x n), L (n x n; A's storage takes R = inv(L^T) afterwards), b
 // (N_d x K, word-major) and sqrt(c) -- plain loops in the order the reference's expressions imply (sums over words and over
 // topics ascending), a left-looking column Cholesky (two barriers per column), back substitution with one thread per column.
-// phi goes to beta_ss and nu to the replicated sigma_ss accumulators with fp64 atomics (like post_big_kernel), so two runs
-// agree to rounding, not bit for bit.  The reference takes any K (stm.py:311-329); K <= 128 has the matrix-core kernels.
+// WM (K <= 128): phi leaves as the scalar r_dw per (document, word) for the word-major beta_ss pass (stm_betass.h) and nu is summed into
+// the workgroup's own n x n slab by plain read-modify-write -- no atomics, run-to-run identical like the matrix-core kernels.  Beyond 128
+// topics (the pass holds two topics per lane) phi goes to beta_ss and nu to replicated accumulators with fp64 atomics: two runs agree to
+// rounding, not bit for bit.  The reference takes any K (stm.py:311-329); K <= 112 has the matrix-core kernels.
 #pragma once
 #include "stm_post_common.h"
 
@@ -24,6 +26,7 @@ __host__ __device__ inline size_t post_any_scratch(int K, int nd_max) {
 // doubles of dynamic LDS: exp(eta~) | stable_softmax(eta~) | eta - mu | rowsum(c') | the reduction tree | scalars
 __host__ __device__ inline size_t post_any_lds_doubles(int K) { return 4 * (size_t)K + ANY_BS + 8; }
 
+template <bool WM>
 __global__ __launch_bounds__(ANY_BS) void post_any_kernel(PostParams P) {
     extern __shared__ __attribute__((aligned(16))) double any_lds[];
     const int tid = threadIdx.x;
@@ -33,7 +36,10 @@ __global__ __launch_bounds__(ANY_BS) void post_any_kernel(PostParams P) {
     double *A = P.a_scratch + (size_t)blockIdx.x * per_wg, *L = A + (size_t)n * n, *bm = L + (size_t)n * n;
     double *sqv = bm + (size_t)P.nd_max * K;
     const double *S = P.siginv;
-    double *sig_acc = P.sigma_part + (size_t)(blockIdx.x % P.nrep) * (size_t)n * n;
+    double *sig_acc = P.sigma_part + (size_t)(WM ? blockIdx.x : blockIdx.x % P.nrep) * (size_t)n * n;
+    auto nu_add = [&](double *cell, double t) __attribute__((always_inline)) {   // (WM: the slab is this workgroup's, a cell one thread's)
+        if constexpr (WM) *cell += t; else unsafeAtomicAdd(cell, t);
+    };
 
     // fixed-order tree over the workgroup (every thread gets the total)
     auto block_sum = [&](double v) -> double {
@@ -107,6 +113,7 @@ __global__ __launch_bounds__(ANY_BS) void post_any_kernel(PostParams P) {
                 Lw += ths[k] * a;
             }
             const double sq = sqrt(c), w = sq / Sw;
+            if constexpr (WM) P.rw[P.wm_slot[p0 + v]] = (w * sq) * sumex;     // r_dw (stm_betass.h): phi = beta theta r
             ll += log(Lw) * c;
             csum += c;
             sqv[v] = sq;
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(ANY_BS) void post_any_kernel(PostParams P) {
                 const double a = row[k] * ex[k];
                 bv[k] = a * sq / Sw;                                  // hessian's b
                 const double ph = a * w * sq;                        // update_z's phi
-                if (!(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + k, ph);
+                if (!WM && !(P.debug_flags & 1)) unsafeAtomicAdd(bssT + (size_t)idx * K + k, ph);
                 if (dump_phi) P.phi_out[(size_t)k * Nd + v] = ph;
             }
         }
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(ANY_BS) void post_any_kernel(PostParams P) {
             if (upper) {   // triu(U^T) = diag(U): nu = diag(1 / L_ii^2)
                 for (int i = tid; i < n; i += ANY_BS) {
                     const double r = 1.0 / L[(size_t)i * n + i];
-                    unsafeAtomicAdd(sig_acc + (size_t)i * n + i, r * r);
+                    nu_add(sig_acc + (size_t)i * n + i, r * r);
                     if (nu_doc)
                         for (int j = 0; j < n; ++j) nu_doc[(size_t)i * n + j] = (j == i) ? r * r : 0.0;
                 }
@@ -260,8 +267,8 @@ __global__ __launch_bounds__(ANY_BS) void post_any_kernel(PostParams P) {
                     double t = 0.0;
                     const double *ri = R + (size_t)i * n, *rj = R + (size_t)j * n;
                     for (int l = j; l < n; ++l) t += ri[l] * rj[l];
-                    unsafeAtomicAdd(sig_acc + (size_t)i * n + j, t);
-                    if (i != j) unsafeAtomicAdd(sig_acc + (size_t)j * n + i, t);
+                    nu_add(sig_acc + (size_t)i * n + j, t);
+                    if (i != j) nu_add(sig_acc + (size_t)j * n + i, t);
                     if (nu_doc) { nu_doc[(size_t)i * n + j] = t; nu_doc[(size_t)j * n + i] = t; }
                 }
             }

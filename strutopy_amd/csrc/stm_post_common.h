@@ -1,4 +1,4 @@
-// stm_post_common.h -- what the post-solve kernels (stm_post.h for K <= 64, stm_post_big.h for 64 < K <= 128) share:
+// stm_post_common.h -- what the post-solve kernels (stm_post.h for K <= 64, stm_post_big2.h for 64 < K <= 112, stm_post_any.h beyond) share:
 // the parameter block, the Cholesky pivot tolerance, the fixed-order reductions of the replicated nu accumulators and of
 // the per-document bounds (reference src/modules/stm.py:582, 592).
 #pragma once
@@ -35,10 +35,9 @@ struct PostParams {
     int debug_flags;       // timing experiments only: 1 skip phi atomics, 2 skip b b^T, 4 skip nu, 8 skip Cholesky;
                            // 16 (tests): NaN into the whole LDS allocation before every document
     int lds_doubles;       // size of the dynamic LDS allocation
-    double *a_scratch;     // post_big_kernel: [grid][n][n] A = H + fixes, upper triangle (per-workgroup scratch)
+    double *a_scratch;     // post_any_kernel: per-workgroup HBM scratch (A, L, b, sqrt(c))
     int64_t phi_doc;       // document whose phi is dumped (-1: none)
     double *phi_out;       // [K][Nd(phi_doc)]
-    int MLD;               // leading dimension of the LDS matrix (odd, >= n)
     long long *prof;       // optional [N][PROF_SLOTS] (shared with the solver's): [32..39] post-kernel phase cycles
     double *rw;            // post_kernel (K <= 64): [nnz] r_dw of stm_betass.h, word-major ...
     const int32_t *wm_slot; // ... at wm_slot[CSR position]

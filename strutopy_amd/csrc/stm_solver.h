@@ -65,6 +65,9 @@
 #ifndef STM_PREFETCH
 #define STM_PREFETCH 1     // persistent two-wave form: wave 1 touches the next document's CSR / eta / mu lines while it waits for the first evaluation
 #endif
+#ifndef STM_C0_LDS
+#define STM_C0_LDS 1       // DMA form: the register word's count parked in the LDS (see its use)
+#endif
 #ifndef STM_FUSE_GROUP
 #define STM_FUSE_GROUP 4   // topics per scheduling group of the side-by-side three-sum passes (twelve chains)
 #endif
@@ -779,10 +782,21 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             __syncthreads();  // slab stores -> visible to the whole wave
         }
         if (bad_all) {
+            // (a persistent workgroup drops the tickets it would still have taken: STM_ERR_BETA is fatal to the E-step -- the host raises
+            // the reference's assert, stm.py:534 -- so eta / status / nit of the documents left untouched are never looked at)
             atomicMax(P.err_flag, 2 /* STM_ERR_BETA */);
             return;
         }
         Ndoc = (double)(long long)csum_all;  // int(np.sum(word_count)), stm.py:933
+#if STM_C0_LDS
+        // DMA form: the count of the lane's register word waits in the LDS, behind the BFGS matrix, where the staging rows of the set-up
+        // were (both waves are past them: the barrier above) -- an evaluation uses it once, at its very end, and two registers held
+        // through the whole document for that were what the allocator spilled (read back from scratch in front of every wave sum)
+        if constexpr (DMA) Hs[(size_t)n * n + tid] = c0;
+#define STM_C0 (DMA ? Hs[(size_t)n * n + tid] : c0)
+#else
+#define STM_C0 c0
+#endif
         if (!DMA && COOP && NdL > 0) {
             // lane = word again for the column sums of the slab rows (same order of additions as the per-lane gather loop);
             // only this wave reads crow / wrow before the next hand-off
@@ -1139,7 +1153,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
 #else
                     log_pos2(sums, lg);
 #endif
-                    part = (wreg < Nd) ? c0 * (m + lg[0]) : 0.0;
+                    part = (wreg < Nd) ? STM_C0 * (m + lg[0]) : 0.0;
                     part += (lane < NdL) ? crow[ia] * (m + lg[1]) : 0.0;
                     return part;
                 }
@@ -1157,7 +1171,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const double lg = m + log_pos(s0 + s1);
-                part = (wreg < Nd) ? c0 * lg : 0.0;
+                part = (wreg < Nd) ? STM_C0 * lg : 0.0;
             }
             if constexpr (DIRECT) {   // re-gather tile by tile; lane = (word, quarter of the topics)
                 tile_fetch(0);
@@ -1822,7 +1836,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                     const double sums[2] = {reg_dot(), u};
                     double lg[2];
                     log_pos2(sums, lg);
-                    part = wave_sum((wreg < Nd) ? c0 * (m + lg[0]) : 0.0);
+                    part = wave_sum((wreg < Nd) ? STM_C0 * (m + lg[0]) : 0.0);
                     lse = ((u == INFINITY) ? lg[1] : lg[1] + cr * __builtin_amdgcn_rcp(u)) + m;
                 } else {
                     if (LATE) lse = lse_tail(m, icnt, stot);

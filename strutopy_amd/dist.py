@@ -118,6 +118,16 @@ def _encode(obj):
     return b"".join(out)
 
 
+def sendable(obj):
+    """"" when the host group can carry `obj`, else why not (what _enc would raise) -- asked before a collective, so that a rank
+    does not find out alone, inside it."""
+    try:
+        _enc(obj, [])
+        return ""
+    except (TypeError, ValueError) as e:
+        return f"{type(e).__name__}: {e}"
+
+
 def _dec(buf, pos):
     tag = buf[pos:pos + 1]
     pos += 1

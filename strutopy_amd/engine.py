@@ -9,7 +9,10 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import check, dptr, f64, iptr, lptr
+from ._lib import dptr, f64, iptr, lptr
+
+
+check = _lib.check   # (the product library's error string; an engine on the testing build passes its own)
 
 
 def device_count():
@@ -20,14 +23,25 @@ def device_count():
 
 
 class HipEstepEngine:
-    def __init__(self, device=0):
-        self._L = _lib.lib()
+    def __init__(self, device=0, testing=False, debug=None):
+        """testing=True: the -DSTM_TESTING build of the library (strutopy_amd/libstm_hip_testing.so) -- the only one with debug
+        switches; `debug`: {"STM_DEBUG_DUMP": 1, ...} set on the handle before the corpus (tests and tools)."""
+        self._L = _lib.lib(testing=testing or bool(debug))
         self._h = C.c_void_p()
-        check(self._L.stm_create(C.byref(self._h), int(device)))
+        self.check(self._L.stm_create(C.byref(self._h), int(device)))
+        for k, v in (debug or {}).items():
+            self.debug_set(k, v)
         self.device = int(device)
         self.N = self.V = self.K = self.A = 0
         self.indptr = None
         self.last_bound = 0.0
+
+    def check(self, rc):
+        _lib.check(rc, self._L)
+
+    def debug_set(self, name, value):
+        """A debug switch (named like its environment variable) on the live handle; the product build refuses."""
+        self.check(self._L.stm_debug_set(self._h, name.encode(), int(value)))
 
     # -- lifetime -----------------------------------------------------------------
     def close(self):
@@ -45,7 +59,7 @@ class HipEstepEngine:
         name = C.create_string_buffer(256)
         cu = C.c_int(0)
         hbm = C.c_int64(0)
-        check(self._L.stm_device_info(self._h, name, 256, C.byref(cu), C.byref(hbm)))
+        self.check(self._L.stm_device_info(self._h, name, 256, C.byref(cu), C.byref(hbm)))
         return dict(name=name.value.decode(), cu=cu.value, hbm_bytes=hbm.value)
 
     # -- corpus / model state ---------------------------------------------------------
@@ -56,13 +70,13 @@ class HipEstepEngine:
         asp = None
         if aspect is not None and A > 1:
             asp = np.ascontiguousarray(aspect, dtype=np.int32)
-        check(self._L.stm_set_corpus(self._h, len(indptr) - 1, int(V), lptr(indptr), iptr(indices),
+        self.check(self._L.stm_set_corpus(self._h, len(indptr) - 1, int(V), lptr(indptr), iptr(indices),
                                      dptr(counts), iptr(asp) if asp is not None else None, int(A)))
         self.N, self.V, self.A = len(indptr) - 1, int(V), int(max(A, 1))
         self.indptr = indptr
 
     def set_topics(self, K):
-        check(self._L.stm_set_topics(self._h, int(K)))
+        self.check(self._L.stm_set_topics(self._h, int(K)))
         self.K = int(K)
 
     def _beta_shape(self):
@@ -72,19 +86,19 @@ class HipEstepEngine:
         beta = f64(beta)
         if beta.shape != self._beta_shape():
             raise ValueError(f"beta has shape {beta.shape}, expected {self._beta_shape()}")
-        check(self._L.stm_put_beta(self._h, dptr(beta)))
+        self.check(self._L.stm_put_beta(self._h, dptr(beta)))
 
     def put_eta(self, eta):
         eta = f64(eta).reshape(self.N, self.K - 1)
-        check(self._L.stm_put_eta(self._h, dptr(eta)))
+        self.check(self._L.stm_put_eta(self._h, dptr(eta)))
 
     def put_mu(self, mu):
         mu = f64(mu).reshape(self.N, self.K - 1)
-        check(self._L.stm_put_mu(self._h, dptr(mu)))
+        self.check(self._L.stm_put_mu(self._h, dptr(mu)))
 
     def _get(self, fn, shape):
         out = np.empty(shape, dtype=np.float64)
-        check(fn(self._h, dptr(out)))
+        self.check(fn(self._h, dptr(out)))
         return out
 
     def get_beta(self):
@@ -107,11 +121,11 @@ class HipEstepEngine:
 
     def put_sigma_ss(self, s):
         s = f64(s).reshape(self.K - 1, self.K - 1)
-        check(self._L.stm_put_sigma_ss(self._h, dptr(s)))
+        self.check(self._L.stm_put_sigma_ss(self._h, dptr(s)))
 
     def put_beta_ss(self, b):
         b = f64(b).reshape(self._beta_shape())
-        check(self._L.stm_put_beta_ss(self._h, dptr(b)))
+        self.check(self._L.stm_put_beta_ss(self._h, dptr(b)))
 
     def get_bound_total(self):
         return self.last_bound
@@ -122,18 +136,18 @@ class HipEstepEngine:
     def get_phi_last(self):
         nd = int(self.indptr[-1] - self.indptr[-2])
         out = np.empty((self.K, nd))
-        check(self._L.stm_get_phi(self._h, self.N - 1, dptr(out)))
+        self.check(self._L.stm_get_phi(self._h, self.N - 1, dptr(out)))
         return out
 
     def get_diagnostics(self):
         out = {k: np.empty(self.N, dtype=np.int32) for k in ("status", "nit", "nfev", "njev", "pd_path")}
-        check(self._L.stm_get_diagnostics(self._h, *(iptr(out[k]) for k in ("status", "nit", "nfev", "njev", "pd_path"))))
+        self.check(self._L.stm_get_diagnostics(self._h, *(iptr(out[k]) for k in ("status", "nit", "nfev", "njev", "pd_path"))))
         return out
 
     def debug_mats(self):
         n = self.K - 1
         hess, chol, nu = (np.empty((self.N, n, n)) for _ in range(3))
-        check(self._L.stm_debug_get_mats(self._h, dptr(hess), dptr(chol), dptr(nu)))
+        self.check(self._L.stm_debug_get_mats(self._h, dptr(hess), dptr(chol), dptr(nu)))
         return hess, chol, nu
 
     # -- the hot path -----------------------------------------------------------------
@@ -141,22 +155,26 @@ class HipEstepEngine:
         """Run the E-step kernels on the resident state; returns the summed bound."""
         siginv = f64(siginv).reshape(self.K - 1, self.K - 1)
         tot = C.c_double(0.0)
-        check(self._L.stm_estep(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot)))
+        self.check(self._L.stm_estep(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot)))
         self.last_bound = tot.value
         return tot.value
 
     def kernel_ms(self):
+        """HIP-event times of the last E-step: solver kernel, post kernel + beta_ss pass ("post"), the pass alone, first to last kernel."""
         ms = (C.c_float * 3)()
-        check(self._L.stm_last_kernel_ms(self._h, ms))
-        return dict(solver=ms[0], post=ms[1], estep=ms[2])
+        self.check(self._L.stm_last_kernel_ms(self._h, ms))
+        ps = C.c_float(0.0)
+        if hasattr(self._L, "stm_last_pass_ms"):      # (absent from an older build loaded for an A/B run)
+            self.check(self._L.stm_last_pass_ms(self._h, C.byref(ps)))
+        return {"solver": ms[0], "post": ms[1], "estep": ms[2], "pass": ps.value}
 
     def synchronize(self):
-        check(self._L.stm_synchronize(self._h))
+        self.check(self._L.stm_synchronize(self._h))
 
     # -- M-step pieces ---------------------------------------------------------------
     def put_covariates(self, X):
         X = f64(X).reshape(self.N, -1)
-        check(self._L.stm_put_covariates(self._h, dptr(X), X.shape[1]))
+        self.check(self._L.stm_put_covariates(self._h, dptr(X), X.shape[1]))
         self.p = X.shape[1]
 
     def moments(self, p):
@@ -164,22 +182,22 @@ class HipEstepEngine:
         n = self.K - 1
         L = 1 + p + n + p * p + p * n + n * n
         out = np.zeros(L)
-        check(self._L.stm_mstep_moments(self._h, dptr(out), L))
+        self.check(self._L.stm_mstep_moments(self._h, dptr(out), L))
         return out
 
     def set_mu_regression(self, gamma):
         gamma = f64(gamma)
-        check(self._L.stm_mstep_set_mu(self._h, dptr(gamma), None))
+        self.check(self._L.stm_mstep_set_mu(self._h, dptr(gamma), None))
 
     def set_mu_constant(self, mean_eta):
         mean_eta = f64(mean_eta)
-        check(self._L.stm_mstep_set_mu(self._h, None, dptr(mean_eta)))
+        self.check(self._L.stm_mstep_set_mu(self._h, None, dptr(mean_eta)))
 
     def covariance(self):
         return self._get(self._L.stm_mstep_covariance, (self.K - 1, self.K - 1))
 
     def update_beta(self):
-        check(self._L.stm_mstep_update_beta(self._h))
+        self.check(self._L.stm_mstep_update_beta(self._h))
 
     # -- the whole iteration with one host wait ------------------------------------------------
     def em_begin(self, siginv, sigmaentropy, p):
@@ -189,7 +207,7 @@ class HipEstepEngine:
         tot = C.c_double(0.0)
         sig = np.empty((n, n))
         mom = np.empty(1 + p + n + p * p + p * n + n * n)
-        check(self._L.stm_em_begin(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot), dptr(sig), dptr(mom), len(mom)))
+        self.check(self._L.stm_em_begin(self._h, dptr(siginv), float(sigmaentropy), C.byref(tot), dptr(sig), dptr(mom), len(mom)))
         self.last_bound = tot.value
         return tot.value, sig, mom
 
@@ -197,7 +215,7 @@ class HipEstepEngine:
         """mu and beta of the M-step, enqueued behind the E-step (no wait)."""
         g = None if gamma is None else f64(gamma)
         m = None if mean_eta is None else f64(mean_eta)
-        check(self._L.stm_em_finish(self._h, dptr(g) if g is not None else None, dptr(m) if m is not None else None))
+        self.check(self._L.stm_em_finish(self._h, dptr(g) if g is not None else None, dptr(m) if m is not None else None))
 
     # -- held-out likelihood ---------------------------------------------------------------
     def eval_heldout(self, indptr, indices, counts, theta=None):
@@ -208,14 +226,14 @@ class HipEstepEngine:
         n = len(indptr) - 1
         th = None if theta is None else f64(theta).reshape(n, self.K)
         out = np.empty(n, dtype=np.float64)
-        check(self._L.stm_eval_heldout(self._h, n, lptr(indptr), iptr(indices), dptr(counts),
+        self.check(self._L.stm_eval_heldout(self._h, n, lptr(indptr), iptr(indices), dptr(counts),
                                        dptr(th) if th is not None else None, dptr(out)))
         return out
 
     # -- spectral initialisation (stm.py:30-296) ----------------------------------------------
     def spectral_gram(self, N, Vk, g):
         a = {k: np.ascontiguousarray(v) for k, v in g.items()}
-        check(self._L.stm_spectral_gram(self._h, int(N), int(Vk), lptr(a["doc_ptr"]), iptr(a["doc_word"]), dptr(a["doc_h"]),
+        self.check(self._L.stm_spectral_gram(self._h, int(N), int(Vk), lptr(a["doc_ptr"]), iptr(a["doc_word"]), dptr(a["doc_h"]),
                                         lptr(a["word_ptr"]), iptr(a["word_doc"]), dptr(a["word_h"]), dptr(f64(a["hhat"]))))
         self._Vk = int(Vk)
 
@@ -223,63 +241,69 @@ class HipEstepEngine:
         """gram over the resident corpus (this rank's shard), restricted to the kept terms; check=False: the caller
         sums the shards' matrices (spectral_allreduce / spectral_put_q) and then calls spectral_check."""
         keep = np.ascontiguousarray(keep, dtype=np.int32)
-        _lib.check(self._L.stm_spectral_gram_resident(self._h, len(keep), iptr(keep), 0 if check else 1))
+        self.check(self._L.stm_spectral_gram_resident(self._h, len(keep), iptr(keep), 0 if check else 1))
         self._Vk = len(keep)
 
     def spectral_terms(self):
         return self._Vk
 
     def spectral_allreduce(self):
-        check(self._L.stm_spectral_allreduce(self._h))
+        self.check(self._L.stm_spectral_allreduce(self._h))
 
     def spectral_put_q(self, Q):
         Q = np.ascontiguousarray(Q, dtype=np.float64)
         assert Q.shape == (self._Vk, self._Vk)
-        check(self._L.stm_spectral_put_q(self._h, dptr(Q)))
+        self.check(self._L.stm_spectral_put_q(self._h, dptr(Q)))
 
     def spectral_check(self):
-        check(self._L.stm_spectral_check(self._h))
+        self.check(self._L.stm_spectral_check(self._h))
 
     def spectral_q_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         out = np.empty((len(rows), self._Vk))
-        check(self._L.stm_spectral_get_q(self._h, iptr(rows), len(rows), dptr(out)))
+        self.check(self._L.stm_spectral_get_q(self._h, iptr(rows), len(rows), dptr(out)))
         return out
 
     def spectral_anchors(self, K):
         out = np.zeros(int(K), dtype=np.int32)
-        check(self._L.stm_spectral_anchors(self._h, int(K), iptr(out)))
+        self.check(self._L.stm_spectral_anchors(self._h, int(K), iptr(out)))
         return out
 
     def spectral_project(self, anchor):
         anchor = np.ascontiguousarray(anchor, dtype=np.int32)
         out = np.empty((self._Vk, len(anchor)))
-        check(self._L.stm_spectral_project(self._h, len(anchor), iptr(anchor), dptr(out)))
+        self.check(self._L.stm_spectral_project(self._h, len(anchor), iptr(anchor), dptr(out)))
         return out
 
     def spectral_weights(self, anchor):
         anchor = np.ascontiguousarray(anchor, dtype=np.int32)
         out = np.empty((self._Vk, len(anchor)))
-        check(self._L.stm_spectral_weights(self._h, len(anchor), iptr(anchor), dptr(out)))
+        self.check(self._L.stm_spectral_weights(self._h, len(anchor), iptr(anchor), dptr(out)))
         return out
 
     def spectral_release(self):
-        check(self._L.stm_spectral_release(self._h))
+        self.check(self._L.stm_spectral_release(self._h))
 
     # -- multi-GPU ---------------------------------------------------------------------
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)
-        check(self._L.stm_comm_unique_id(buf))
+        self.check(self._L.stm_comm_unique_id(buf))
         return buf.raw
 
     def comm_init(self, uid, rank, nranks):
         buf = C.create_string_buffer(uid, 128)
-        check(self._L.stm_comm_init(self._h, buf, int(rank), int(nranks)))
+        self.check(self._L.stm_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def set_exchange(self, mode):
+        """"split" (two all-reduces per EM iteration, beta_ss behind the read-back) | "single" (one, of the whole packed buffer)."""
+        if mode not in ("split", "single"):
+            raise ValueError("exchange must be 'split' or 'single'")
+        self.check(self._L.stm_comm_set_exchange(self._h, 1 if mode == "single" else 0))
 
     def comm_info(self):
         """RCCL's own view of this handle's communicator: dict(nranks, rank, device); nranks = 0 without one."""
         n, r, d = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-        check(self._L.stm_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        self.check(self._L.stm_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
         return dict(nranks=n.value, rank=r.value, device=d.value)
 
     def allreduce_suffstats(self, moments):
@@ -287,19 +311,20 @@ class HipEstepEngine:
         (bound, reduced moments).  `moments` is what moments() returned (its values already sit in the buffer)."""
         out = np.zeros(len(np.asarray(moments).ravel()))
         tot = C.c_double(0.0)
-        check(self._L.stm_allreduce_suffstats(self._h, C.byref(tot), dptr(out) if len(out) else None, len(out)))
+        self.check(self._L.stm_allreduce_suffstats(self._h, C.byref(tot), dptr(out) if len(out) else None, len(out)))
         return tot.value, out
 
     def allreduce_small(self, buf):
         buf = f64(buf).copy()
         flat = buf.reshape(-1)
-        check(self._L.stm_allreduce_small(self._h, dptr(flat), flat.size))
+        self.check(self._L.stm_allreduce_small(self._h, dptr(flat), flat.size))
         return buf
 
 
-def estep_host(indptr, indices, counts, beta, mu, eta, siginv, sigmaentropy, aspect=None, device=0):
-    """One-shot E-step over host arrays through stm_estep_host (upload, run, download)."""
-    L = _lib.lib()
+def estep_host(indptr, indices, counts, beta, mu, eta, siginv, sigmaentropy, aspect=None, device=0, testing=False):
+    """One-shot E-step over host arrays through stm_estep_host (upload, run, download).  testing=True: through the -DSTM_TESTING
+    build, whose handles read the STM_DEBUG_* environment switches when they are created (tests)."""
+    L = _lib.lib(testing=testing)
     beta = f64(beta)
     if beta.ndim == 2:
         A, (K, V) = 1, beta.shape
@@ -330,6 +355,6 @@ def estep_host(indptr, indices, counts, beta, mu, eta, siginv, sigmaentropy, asp
         dptr(out["theta"]), dptr(out["bound_doc"]), dptr(out["sigma_ss"]), dptr(out["beta_ss"]), dptr(tot))
     for k in ("status", "nit", "nfev", "njev", "pd_path"):
         setattr(a, k, iptr(out[k]))
-    check(L.stm_estep_host(C.byref(a), int(device)))
+    _lib.check(L.stm_estep_host(C.byref(a), int(device)), L)
     out["bound"] = float(tot[0])
     return out

@@ -27,6 +27,7 @@ from .corpus import PackedCorpus, pack_bow
 from .dist import SingleComm
 
 logger = logging.getLogger(__name__)
+_GATHER_BLOCK = 256 << 20     # bytes per rank and message when save_model gathers the shards' rows
 
 
 def _default_engine(device):
@@ -127,13 +128,17 @@ class STM:
     def __init__(self, documents, dictionary, content, K, X, kappa_interactions, max_em_iter,
                  sigma_prior, convergence_threshold, lda_beta=True, beta_index=None, A=None,
                  dtype=np.float32, init_type="spectral", model_type="STM", mode="ols",
-                 device=0, comm=None, engine=None, n_total=None):
+                 device=0, comm=None, engine=None, n_total=None, exchange="split"):
         """Same arguments as the reference constructor (stm.py:311-329) plus
 
         device  : GPU ordinal of this process
         comm    : strutopy_amd.dist communicator when `documents` is one shard of a
                   document-sharded corpus (None: single GPU)
         engine  : test hook -- an object with the HipEstepEngine interface
+        exchange: "split" (default) | "single" -- how a sharded fit's EM iteration sends its sufficient statistics over RCCL: two
+                  all-reduces ([bound | sigma_ss | moments] in front of the host's read-back, beta_ss behind it) or ONE of the whole
+                  packed buffer (what BASELINE.json's north_star names); same sums (`STM.exchange` can be changed between iterations,
+                  on every rank alike)
         `documents` may be the reference's BoW list or a strutopy_amd.corpus.PackedCorpus.
         """
         np.random.seed(123456)  # stm.py:361 reseeds numpy's legacy global RNG; kept for drop-in parity
@@ -190,6 +195,10 @@ class STM:
         self._cov_on_device = False
         self._phi = None
         self._phi_stale = False
+        if exchange not in ("split", "single"):
+            raise ValueError("exchange must be 'split' or 'single'")
+        self.exchange = exchange
+        self._exchange_set = None
         self.cov_exchange = "moments"    # "exact": always take the second (K-1)^2 all-reduce of the local covariance
         self.cov_exchanges = []          # per resident iteration: which form was used
         # which side holds the fresh copy of each array ("host" | "device" | "both")
@@ -222,10 +231,7 @@ class STM:
     def phi(self):
         """stm.py:1116 leaves the last document's phi in self.phi; fetched from the device on first use."""
         if self._phi_stale:
-            try:
-                self._phi = self._engine.get_phi_last()
-            except Exception:
-                self._phi = None
+            self._phi = self._engine.get_phi_last()     # (a failing read-back raises: the reference leaves a matrix here, never None)
             self._phi_stale = False
         return self._phi
 
@@ -431,6 +437,9 @@ class STM:
             self._preamble()
             for name in ("beta", "eta", "mu"):
                 self._push(name)
+            if self._exchange_set != self.exchange and hasattr(eng, "set_exchange") and (self.exchange != "split" or self._exchange_set is not None):
+                eng.set_exchange(self.exchange)       # ("split" is a fresh handle's state)
+            self._exchange_set = self.exchange
             bound, sigma_ss, mom = eng.em_begin(self.siginv, float(self.sigmaentropy), p)
             self._fresh["eta"] = self._fresh["theta"] = "device"
             self._phi_stale = True
@@ -550,13 +559,38 @@ class STM:
         if comm.size <= 1:
             self._write_model(output_dir, self.theta, self.eta, self.mu, self.X)
             return
+        from .dist import sendable
         rows = {}
         for name in ("theta", "eta", "mu", "X"):
             part = getattr(self, name)
             part = None if part is None else np.asarray(part)
-            parts = comm.gather(part, 0)
+            # what every rank is about to send, agreed on BEFORE anything travels: a rank whose shard cannot be sent (an X dtype the
+            # host group does not carry) or that holds nothing where others hold rows raises on EVERY rank here, instead of failing
+            # alone inside the gather while rank 0 waits for it
+            why = "" if part is None else sendable(part[:1])
+            info = comm.allgather((None if part is None else (tuple(part.shape), int(part[:1].nbytes)), why))
+            bad = [f"rank {r}: {w}" for r, (_, w) in enumerate(info) if w]
+            if bad:
+                raise RuntimeError(f"save_model: {name} cannot be gathered ({'; '.join(bad)})")
+            if any(i[0] is None for i in info):
+                if not all(i[0] is None for i in info):
+                    raise RuntimeError(f"save_model: {name} is None on some ranks only")
+                rows[name] = None
+                continue
+            # row blocks of at most _GATHER_BLOCK bytes per rank and message (a shard of any size stays below the host group's frame
+            # limit, and rank 0 never holds more than one block per rank beside the array it assembles)
+            row_bytes = max(max(i[0][1] for i in info), 1)
+            per = max(1, _GATHER_BLOCK // row_bytes)
+            nblk = max((i[0][0][0] + per - 1) // per for i in info)
+            got = [[] for _ in range(comm.size)]
+            for b in range(max(nblk, 1)):
+                parts = comm.gather(part[b * per:(b + 1) * per], 0)
+                if comm.rank == 0:
+                    for r, q in enumerate(parts):
+                        if len(q):
+                            got[r].append(q)
             if comm.rank == 0:
-                rows[name] = None if any(q is None for q in parts) else np.concatenate(parts, axis=0)
+                rows[name] = np.concatenate([q for r in got for q in r], axis=0) if any(got) else part[:0]
         err = ""
         if comm.rank == 0:
             try:

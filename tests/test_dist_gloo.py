@@ -45,7 +45,8 @@ def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="
     X = _covariate(g, xkind)
     m = STM(documents=full.slice(lo, hi), dictionary=None, content=False, K=int(g["K"]), X=X[lo:hi],
             kappa_interactions=False, max_em_iter=iters, sigma_prior=0, convergence_threshold=1e-12,
-            init_type=init, model_type=model_type, mode=mode, comm=comm, engine=OracleEngine(nthreads=1))
+            init_type=init, model_type=model_type, mode=mode, comm=comm, engine=OracleEngine(nthreads=1),
+            exchange="single" if rank_exchange_single(xkind) else "split")   # (the host reduction is one packed message either way)
     assert m.N_total == full.N
     m.expectation_maximization(saving=outdir is not None, output_dir=outdir)
     d = m.solver_diagnostics()
@@ -58,6 +59,10 @@ def _worker(rank, world, port, case, model_type, iters, q, group="gloo", xkind="
         tdist.destroy_process_group()
     else:
         comm.group.close()
+
+
+def rank_exchange_single(xkind):
+    return xkind == "sorted3"
 
 
 def _covariate(g, xkind):

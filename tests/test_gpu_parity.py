@@ -85,10 +85,9 @@ def test_wiki_known_answer_shipped_by_reference():
 
 def test_hessian_cholesky_nu_per_document(monkeypatch):
     from strutopy_amd.engine import HipEstepEngine
-    monkeypatch.setenv("STM_DEBUG_DUMP", "1")
     for name in ("toy_ctm", "edge"):
         g = load_golden(name)
-        e = HipEstepEngine(0)
+        e = HipEstepEngine(0, debug={"STM_DEBUG_DUMP": 1})   # (the -DSTM_TESTING build: the product library has no debug switches)
         e.set_corpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
         e.set_topics(int(g["K"]))
         e.put_beta(g["beta0"]); e.put_mu(g["it0_mu_in"]); e.put_eta(g["it0_eta_in"])
@@ -107,7 +106,7 @@ def test_hessian_cholesky_nu_per_document(monkeypatch):
 def test_shapes_at_the_limits(oracle, K, nd_max):
     """smallest / largest K of this build (K <= 64: one topic per lane + MFMA post kernel; 64 < K <= 112: two topics per lane
     in the solver, two waves per document in the post step -- 80 | 81 is where its tile pitch changes, 112 | 113 where the
-    one-wave post_big_kernel takes over; K <= 128) and documents longer than one 64-word tile.  18 | 33 | 34 | 49 | 51: every block
+    general post_any_kernel takes over, in its atomics-free form up to K = 128) and documents longer than one 64-word tile.  18 | 33 | 34 | 49 | 51: every block
     count of post_kernel with and without its remainder row (K = 16 NB + 2), i.e. every rows-per-instruction of the tile fetch."""
     from strutopy_amd.engine import estep_host
     rng = np.random.default_rng(K)
@@ -142,10 +141,11 @@ def _random_case(rng, K, V, N, nd_max, dense):
     return indptr, indices, counts, beta, mu, eta, sigma
 
 
-@pytest.mark.parametrize("K,nd_max", [(129, 90), (160, 300), (256, 70), (257, 40), (300, 50)])
+@pytest.mark.parametrize("K,nd_max", [(129, 90), (160, 300), (256, 70), (257, 40), (300, 50), (512, 30)])
 def test_more_than_128_topics(oracle, K, nd_max):
     """K > 128 (the reference takes any K, stm.py:311-329): the solver's general form with four / eight vector components per
-    lane (slab and BFGS matrix in HBM) and post_any_kernel (stm_post_any.h) -- 129 | 256 | 257 are the edges of the two."""
+    lane (slab and BFGS matrix in HBM) and post_any_kernel (stm_post_any.h) -- 129 | 256 | 257 are the edges of the two, 512 the
+    largest K the headers advertise (its per-document HBM state is bounded per launch, not by the corpus)."""
     from strutopy_amd.engine import estep_host
     rng = np.random.default_rng(K)
     indptr, indices, counts, beta, mu, eta, sigma = _random_case(rng, K, 900, 40, nd_max, False)
@@ -178,11 +178,10 @@ def test_general_post_kernel_is_a_second_implementation(oracle, monkeypatch, K, 
 def test_general_post_kernel_matrices_per_document(monkeypatch):
     """H, L and nu of post_any_kernel against the reference's own (toy_ctm / edge goldens: PD ladder paths included)."""
     from strutopy_amd.engine import HipEstepEngine
-    monkeypatch.setenv("STM_DEBUG_DUMP", "1")
     monkeypatch.setenv("STM_POST_ANY", "1")
     for name in ("toy_ctm", "edge"):
         g = load_golden(name)
-        e = HipEstepEngine(0)
+        e = HipEstepEngine(0, debug={"STM_DEBUG_DUMP": 1})
         e.set_corpus(g["indptr"], g["indices"], g["counts"], int(g["V"]))
         e.set_topics(int(g["K"]))
         e.put_beta(g["beta0"]); e.put_mu(g["it0_mu_in"]); e.put_eta(g["it0_eta_in"])
@@ -215,13 +214,13 @@ def test_post_kernels_ignore_stale_lds(oracle, monkeypatch, K, nd_max):
     mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
     siginv, sigent = oracle.preamble(np.eye(n) * 20.0)
     args = (indptr, indices, counts, beta, mu, eta, siginv, sigent)
-    _check(estep_host(*args), oracle.estep(*args, nthreads=0), f"K={K} poisoned LDS")
+    _check(estep_host(*args, testing=True), oracle.estep(*args, nthreads=0), f"K={K} poisoned LDS")
 
 
 @pytest.mark.parametrize("big2", ["1", "0"])
 def test_k100_two_topics_per_lane(oracle, monkeypatch, big2):
     """BASELINE config 4's K = 100: the two-topics-per-lane solver and the post step -- post_big2_kernel (two waves per
-    document; STM_POST_BIG2=1, the default) and the one-wave post_big_kernel it replaced (kept for K > 112 and for A/B runs) --
+    document; STM_POST_BIG2=1, the default) and, with STM_POST_BIG2=0, the general post_any_kernel in its atomics-free form --
     per-document Hessian / Cholesky / nu against the oracle, and the device M-step at n = 99 (resident EM iterations
     against the host-NumPy M-step)."""
     monkeypatch.setenv("STM_POST_BIG2", big2)
@@ -239,8 +238,7 @@ def test_k100_two_topics_per_lane(oracle, monkeypatch, big2):
     n = K - 1
     mu = rng.normal(0, 0.3, size=(N, n)); eta = rng.normal(0, 0.3, size=(N, n))
     siginv, sigent = oracle.preamble(np.eye(n) * 20.0)
-    monkeypatch.setenv("STM_DEBUG_DUMP", "1")
-    e = HipEstepEngine(0)
+    e = HipEstepEngine(0, debug={"STM_DEBUG_DUMP": 1})
     e.set_corpus(indptr, indices, counts, V)
     e.set_topics(K)
     e.put_beta(beta); e.put_mu(mu); e.put_eta(eta)
@@ -248,7 +246,6 @@ def test_k100_two_topics_per_lane(oracle, monkeypatch, big2):
     hess, chol, nu = e.debug_mats()
     phi = e.get_phi_last()
     e.close()
-    monkeypatch.delenv("STM_DEBUG_DUMP")
     o = oracle.estep(indptr, indices, counts, beta, mu, eta, siginv, sigent, dump_mats=True, nthreads=0)
     assert _rel(hess, o["hess"]) <= 1e-9
     assert _rel(chol, o["chol"]) <= 1e-9

@@ -121,13 +121,13 @@ def test_k50_later_iterations_teacher_forced(oracle, monkeypatch, flags):
     16 only the moment pass in front of the first search (round 3): all three must agree with the reference AND
     with each other (the cuts change nothing)."""
     from strutopy_amd.engine import estep_host
-    monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
+    monkeypatch.setenv("STM_DEBUG_FLAGS", flags)     # (read by the -DSTM_TESTING build only: flags 0 runs through the product library)
     g = load_golden("k50_late")
     for it in g["kept"]:
         p = f"it{int(it)}_"
         args = (g["indptr"], g["indices"], g["counts"], g[p + "beta_in"], g[p + "mu_in"], g[p + "eta_in"], g[p + "siginv"],
                 float(g[p + "sigmaentropy"]))
-        d = estep_host(*args)
+        d = estep_host(*args, testing=flags != "0")
         for k in ("status", "nit", "pd_path"):
             assert np.array_equal(d[k], g[p + k]), f"it{it}: {k} differs from the reference in {np.sum(d[k] != g[p + k])} documents"
         assert np.max(np.abs(d["eta"] - g[p + "eta"])) <= 1e-7
@@ -156,7 +156,7 @@ def test_moment_pass_proves_failing_first_searches(monkeypatch):
     out = {}
     for flags in ("0", "16"):
         monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
-        out[flags] = estep_host(*args)
+        out[flags] = estep_host(*args, testing=flags != "0")
     a, b = out["0"], out["16"]
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["nit"], b["nit"])
     assert np.array_equal(a["eta"], b["eta"])
@@ -211,13 +211,14 @@ def test_wiki_k70_known_answer_and_teacher_forced_iteration():
             assert abs(d["bound"] - shipped) <= 1e-9 * abs(shipped)
 
 
-@pytest.mark.parametrize("K", [70, 100])
+@pytest.mark.parametrize("K", [70, 100, 113, 128])
 def test_k_above_64_statistics_are_run_to_run_identical(K):
-    """64 < K <= 112 (post_big2_kernel): no atomics on the data path -- r_dw + the word-major beta_ss pass, nu in per-workgroup
-    slabs, fixed-order reductions -- so beta_ss, sigma_ss and the bound of two E-steps on the same state agree bit for bit."""
+    """64 < K <= 112 (post_big2_kernel) and 112 < K <= 128 (post_any_kernel<WM>; the one-wave kernel of rounds 1-5 with its atomics is
+    gone): no atomics on the data path -- r_dw + the word-major beta_ss pass, nu in per-workgroup slabs, fixed-order reductions --
+    so beta_ss, sigma_ss and the bound of two E-steps on the same state agree bit for bit."""
     from strutopy_amd.corpus import synthetic_corpus
     from strutopy_amd.engine import HipEstepEngine
-    c = synthetic_corpus(3000, 4000, K, n_words=120, seed=K).corpus
+    c = synthetic_corpus(3000 if K <= 112 else 1200, 4000, K, n_words=120, seed=K).corpus
     beta = reference_beta0(K, c.V)
     n = K - 1
     rng = np.random.default_rng(K)
@@ -245,7 +246,7 @@ def test_k_above_64_four_waves_per_document_equal_two(K, monkeypatch):
     are per workgroup: three documents per CU for both) the statistics agree with the two-wave form bit for bit."""
     from strutopy_amd.corpus import synthetic_corpus
     from strutopy_amd.engine import HipEstepEngine
-    c = synthetic_corpus(3000, 4000, K, n_words=120, seed=K).corpus
+    c = synthetic_corpus(3000 if K <= 112 else 1200, 4000, K, n_words=120, seed=K).corpus
     beta = reference_beta0(K, c.V)
     n = K - 1
     rng = np.random.default_rng(K)
@@ -433,16 +434,21 @@ def test_a_rank_that_fails_before_its_first_launch_still_joins_the_collectives(m
     from strutopy_amd.corpus import synthetic_corpus
     syn = synthetic_corpus(600, 1500, 20, n_words=80, seed=21)
 
-    def model():
+    from strutopy_amd.engine import HipEstepEngine
+
+    def model(testing=False):   # (the fault injector exists in the -DSTM_TESTING build only)
         return STM(documents=syn.corpus, dictionary=None, content=False, K=20, X=syn.X, kappa_interactions=False, max_em_iter=3,
-                   sigma_prior=0, convergence_threshold=1e-12, init_type="random", comm=sdist.RcclComm(sdist.TcpGroup(0, 1)))
+                   sigma_prior=0, convergence_threshold=1e-12, init_type="random", comm=sdist.RcclComm(sdist.TcpGroup(0, 1)),
+                   engine=HipEstepEngine(0, testing=testing))
     ref = model()
     ref.expectation_maximization(saving=False)
-    m = model()
-    monkeypatch.setenv("STM_DEBUG_FAIL_PLAN", "1")
+    m = model(testing=True)
+    m._engine.debug_set("STM_DEBUG_FAIL_PLAN", 1)
     with pytest.raises(StmError, match="STM_DEBUG_FAIL_PLAN"):
         m._em_iteration_resident()
-    monkeypatch.delenv("STM_DEBUG_FAIL_PLAN")
+    m._engine.debug_set("STM_DEBUG_FAIL_PLAN", 0)
+    with pytest.raises(ValueError, match="STM_TESTING"):      # ... and the product library refuses debug switches altogether
+        ref._engine.debug_set("STM_DEBUG_FAIL_PLAN", 1)
     m.last_bounds = []
     m.expectation_maximization(saving=False)
     assert np.allclose(m.last_bounds, ref.last_bounds, rtol=1e-12)
@@ -507,6 +513,37 @@ def test_k100_resident_em_through_a_one_rank_rccl_communicator():
             assert np.allclose(got[3], ref[3], rtol=1e-6, atol=1e-12), (kind, form)
         assert res[kind + "-moments"][2].shape == ref[2].shape
     assert np.allclose(res["bin-moments"][2], res["bin-host"][2], rtol=1e-6, atol=1e-8)
+
+
+def test_single_and_split_exchange_give_the_same_fit_through_a_one_rank_rccl_communicator():
+    """STM(exchange="single"): ONE ncclAllReduce of the whole packed buffer [bound | sigma_ss | moments | beta_ss] per EM iteration (the
+    exchange BASELINE.json's north_star names) instead of the default two ("split": beta_ss behind the host's read-back).  Same sums:
+    with a real one-rank communicator both forms -- and a switch from one to the other in the middle of a fit -- give the trace and
+    the parameters of the fit without a communicator, bit for bit."""
+    from strutopy_amd import STM, dist as sdist
+    from strutopy_amd.corpus import synthetic_corpus
+    syn = synthetic_corpus(1500, 3000, 50, n_words=100, seed=5)
+    res = {}
+    for tag in ("none", "split", "single", "switch"):
+        comm = None if tag == "none" else sdist.RcclComm(sdist.TcpGroup(0, 1))
+        m = STM(documents=syn.corpus, dictionary=None, content=False, K=50, X=syn.X, kappa_interactions=False, max_em_iter=4,
+                sigma_prior=0, convergence_threshold=1e-12, init_type="random", comm=comm, exchange="single" if tag == "single" else "split")
+        if tag == "switch":
+            for it in range(4):
+                m.exchange = "single" if it % 2 else "split"
+                m._em_iteration_resident()
+        else:
+            m.expectation_maximization(saving=False)
+        if comm is not None:
+            assert m.comm.kind == "rccl" and m._engine.comm_info()["nranks"] == 1
+        res[tag] = (np.array(m.last_bounds), m.sigma.copy(), m.beta.copy(), m.eta.copy())
+        m.close()
+    with pytest.raises(ValueError):
+        STM(documents=syn.corpus, dictionary=None, content=False, K=50, X=syn.X, kappa_interactions=False, max_em_iter=1, sigma_prior=0,
+            convergence_threshold=1e-12, init_type="random", exchange="both")
+    for tag in ("split", "single", "switch"):
+        for a, b in zip(res[tag], res["none"]):
+            assert np.array_equal(a, b), tag
 
 
 def _free_port():
@@ -681,7 +718,7 @@ def test_long_run_regime_of_config5_is_within_the_oracles_own_sensitivity(oracle
            status / nit / eta, bit for bit: the cuts are not what moves a document there;
       (ii) the HIP path against the oracle, and the oracle against itself from a start moved by a relative 1e-13: the
            number of documents whose nit / status differ between GPU and oracle must not exceed what the oracle's own
-           sensitivity to a perturbation of the last bits produces (with a floor of 1 % of the documents), and eta must
+           sensitivity to a perturbation of the last bits produces (floor: three documents), and eta must
            agree as well as the oracle agrees with itself."""
     from strutopy_amd import STM
     from strutopy_amd.corpus import synthetic_corpus
@@ -689,8 +726,9 @@ def test_long_run_regime_of_config5_is_within_the_oracles_own_sensitivity(oracle
     syn = synthetic_corpus(N, V, K, n_words=150, seed=12345)
     c = syn.corpus
     aspect = np.random.default_rng(777).integers(0, A, size=N).astype(np.int32)
+    from strutopy_amd.engine import HipEstepEngine
     m = STM(documents=c, dictionary=None, content=True, K=K, X=syn.X, kappa_interactions=True, A=A, beta_index=aspect,
-            max_em_iter=200, sigma_prior=0, convergence_threshold=1e-12, init_type="random")
+            max_em_iter=200, sigma_prior=0, convergence_threshold=1e-12, init_type="random", engine=HipEstepEngine(0, testing=True))
     its, mean_nit = 0, 0.0
     while its < 120 and mean_nit < 8.0:
         m._em_iteration_resident()
@@ -703,12 +741,12 @@ def test_long_run_regime_of_config5_is_within_the_oracles_own_sensitivity(oracle
     siginv, sigent = m.siginv.copy(), float(m.sigmaentropy)
     res = {}
     for flags in ("0", "6"):
-        monkeypatch.setenv("STM_DEBUG_FLAGS", flags)
+        m._engine.debug_set("STM_DEBUG_FLAGS", int(flags))
         m.eta = eta.copy()
         m._estep_device()
         d = m.solver_diagnostics()
         res[flags] = (d["status"].copy(), d["nit"].copy(), m.eta.copy(), d["nfev"].copy())
-    monkeypatch.delenv("STM_DEBUG_FLAGS")
+    m._engine.debug_set("STM_DEBUG_FLAGS", 0)
     assert np.array_equal(res["0"][0], res["6"][0]) and np.array_equal(res["0"][1], res["6"][1])
     assert np.array_equal(res["0"][2], res["6"][2])                      # the same bits
     assert res["6"][3].mean() > res["0"][3].mean()                       # (and the cuts did skip evaluations)
@@ -721,10 +759,33 @@ def test_long_run_regime_of_config5_is_within_the_oracles_own_sensitivity(oracle
     gpu_eta = float(np.max(np.abs(res["0"][2] - o["eta"])))
     print(f"long-run regime after {its} EM iterations: mean nit {o['nit'].mean():.2f}; GPU vs oracle: {gpu_nit} nit / {gpu_status} status differ, "
           f"eta {gpu_eta:.2e}; oracle vs oracle(1 + 1e-13): {self_nit} / {self_status}, eta {self_eta:.2e}")
-    floor = N // 100
-    assert gpu_nit <= max(2 * self_nit, floor) and gpu_status <= max(2 * self_status, floor // 4)
+    assert gpu_nit <= max(2 * self_nit, 3) and gpu_status <= max(2 * self_status, 3)
     assert gpu_eta <= max(10 * self_eta, 1e-6)
     m.close()
+
+
+def test_long_run_regime_against_the_reference_on_the_gpu():
+    """tests/golden/c5_long.npz: the imported reference, teacher-forced for one E-step on the state of a config-5-shaped device fit at
+    EM iteration 26 (mean scipy nit 12).  The bar is the reference's own sensitivity there (it differs from itself in `ref_self_nit`
+    of 300 documents when its start moves by a relative 1e-13): the HIP path may differ from the reference in at most
+    max(2 x that, 3) documents, and on the documents that take the reference's path eta agrees within 10 x its eta sensitivity."""
+    from strutopy_amd.engine import estep_host
+    g = load_golden("c5_long")
+    d = estep_host(g["indptr"], g["indices"], g["counts"], g["beta"], g["mu"], g["eta"], g["siginv"], float(g["sigmaentropy"]), aspect=g["aspect"])
+    nit_bar, status_bar = max(2 * int(g["ref_self_nit"]), 3), max(2 * int(g["ref_self_status"]), 3)
+    d_nit, d_status = int(np.sum(d["nit"] != g["out_nit"])), int(np.sum(d["status"] != g["out_status"]))
+    same = (d["nit"] == g["out_nit"]) & (d["status"] == g["out_status"])
+    d_eta = float(np.max(np.abs(d["eta"] - g["out_eta"])[same]))
+    print(f"long-run golden: HIP vs reference {d_nit} nit / {d_status} status of {len(same)} documents differ, eta {d_eta:.2e} on the same path; "
+          f"reference vs itself {int(g['ref_self_nit'])} / {int(g['ref_self_status'])}, {float(g['ref_self_eta']):.2e}; oracle vs reference "
+          f"{int(g['ref_vs_oracle_nit'])} / {int(g['ref_vs_oracle_status'])}")
+    assert g["out_nit"].mean() >= 8.0
+    assert d_nit <= nit_bar and d_status <= status_bar and d_eta <= 10.0 * float(g["ref_self_eta"])
+    assert np.array_equal(d["pd_path"], g["out_pd_path"])
+    assert abs(d["bound"] - float(g["out_bound"])) <= 1e-8 * abs(float(g["out_bound"]))
+    rel = float(np.max(np.abs(d["sigma_ss"] - g["out_sigma_ss"])) / np.max(np.abs(g["out_sigma_ss"])))
+    assert rel <= 1e-6
+    assert np.allclose(d["beta_ss"].sum(axis=-1), g["out_beta_ss_rowsum"], rtol=1e-7) and np.allclose(d["beta_ss"].sum(axis=-2), g["out_beta_ss_colsum"], rtol=1e-6, atol=1e-9)
 
 
 # ------------------------------------------------------------------ config 4 as a corpus: the shards' statistics add up (VERDICT round 4, item 5)

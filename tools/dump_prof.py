@@ -2,6 +2,7 @@
 """Per-document solver state visits at one EM iteration (STM_DEBUG_PROF) for the first documents:  python tools/dump_prof.py <it> [docs] -> gpurun_out/prof_it<N>.npz"""
 import ctypes as C, os, sys
 os.environ["STM_DEBUG_PROF"] = "1"
+os.environ.setdefault("STM_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "strutopy_amd", "libstm_hip_testing.so"))   # debug switches: the -DSTM_TESTING build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -14,7 +14,7 @@ args = (g["indptr"], g["indices"], g["counts"], g["beta"], g["mu"], g["eta"], g[
 o = stm_oracle.estep(*args, aspect=asp, nthreads=0)
 for flags in ("0", "6"):
     os.environ["STM_DEBUG_FLAGS"] = flags
-    d = estep_host(*args, aspect=asp)
+    d = estep_host(*args, aspect=asp, testing=True)   # (STM_DEBUG_FLAGS: the -DSTM_TESTING build)
     bad = np.nonzero((d["nit"] != o["nit"]) | (d["status"] != o["status"]) | (d["pd_path"] != o["pd_path"]))[0]
     print(f"STM_DEBUG_FLAGS={flags}: {len(bad)} documents differ; nfev mean gpu {d['nfev'].mean():.1f} oracle {o['nfev'].mean():.1f}")
     de = np.max(np.abs(d["eta"] - o["eta"]), axis=1)

@@ -637,7 +637,68 @@ def case_mstep_modes():
     save("mstep_modes", **out)
 
 
-CASES = dict(mstep_modes=case_mstep_modes, toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
+def case_long_c5():
+    """The LONG-RUN regime, pinned to the reference: config 5's shape (K = 50, content covariate, A = 2
+    levels of beta, V = 10k) at the first EM iteration of a device fit whose documents take about ten BFGS iterations each
+    (tools/dump_long_state.py -> gpurun_out/c5_long_state.npz: beta, sigma, eta, mu and the CSR of the first 300 documents -- data).
+    The imported reference is TEACHER-FORCED on that state for ONE E-step; per document its status / nit / nfev / eta / bound are the
+    golden.  The oracle's run on the same state is compared here and the counts of documents where it differs from the reference are
+    stored as metadata (`ref_vs_oracle_*`): ten BFGS iterations amplify a last-bit difference into one accepted step more or less
+    (DESIGN section 9), so the tests' bar for the HIP path is the oracle's own distance from the reference, not zero.
+    Without the state file the inputs are taken from the existing golden (re-generation on a new scipy)."""
+    src = os.path.join(REPO, "gpurun_out", "c5_long_state.npz")
+    if not os.path.exists(src):
+        src = os.path.join(OUT, "c5_long.npz")
+    st = np.load(src)
+    K, V, A = int(st["K"]), int(st["V"]), int(st["A"])
+    indptr, idx, cnt = st["indptr"], st["indices"], st["counts"]
+    N = len(indptr) - 1
+    docs = [[(int(idx[q]), int(cnt[q])) for q in range(indptr[d], indptr[d + 1])] for d in range(N)]
+    from gensim.corpora.dictionary import Dictionary
+    dictionary = Dictionary({i: str(i) for i in range(V)})
+    m = make_model(docs, dictionary, K, st["X"], content=True, interactions=True, beta_index=st["aspect"], A=A, max_em_iter=1)
+    assert np.asarray(m.beta).shape == st["beta"].shape, (np.asarray(m.beta).shape, st["beta"].shape)
+    m.beta, m.sigma = st["beta"].copy(), st["sigma"].copy()
+    m.eta, m.mu = st["eta"].copy(), st["mu"].copy()
+    m._rec_reset()
+    t = time.time()
+    beta_ss, sigma_ss = m.E_step()
+    te = time.time() - t
+    assert np.allclose(np.asarray(m.siginv), st["siginv"], rtol=1e-12, atol=0) and np.isclose(float(m.sigmaentropy), float(st["sigmaentropy"]), rtol=1e-12)
+    r = {k: np.asarray(m.rec[k], dtype=np.int32) for k in ("status", "nit", "nfev", "njev", "pd_path")}
+    print(f"    reference: {te:.1f}s, mean nit {r['nit'].mean():.2f}, mean nfev {r['nfev'].mean():.1f}, status {np.bincount(r['status'])}, pd_path {np.bincount(r['pd_path'], minlength=3)}")
+    # the oracle on the same state: how far a faithful restatement lands from scipy itself in this regime (the tests' bar)
+    sys.path.insert(0, REPO)
+    from oracle import stm_oracle
+    o = stm_oracle.estep(indptr, idx, cnt, st["beta"], st["mu"], st["eta"], np.asarray(m.siginv), float(m.sigmaentropy), aspect=st["aspect"].astype(np.int32), nthreads=1)
+    d_nit = int(np.sum(o["nit"] != r["nit"])); d_status = int(np.sum(o["status"] != r["status"]))
+    d_eta = float(np.max(np.abs(o["eta"] - m.eta)))
+    same = (o["nit"] == r["nit"]) & (o["status"] == r["status"])
+    d_eta_same = float(np.max(np.abs(o["eta"] - m.eta)[same])) if same.any() else 0.0
+    d_bound = float(abs(o["bound"] - m.bound) / abs(m.bound))
+    print(f"    oracle vs reference: nit differs in {d_nit} / {N} documents, status in {d_status}; eta max abs {d_eta:.3e} (documents with equal nit / status: {d_eta_same:.3e}); ELBO rel {d_bound:.3e}")
+    # ... and the reference against itself from a start moved by a relative 1e-13: its own sensitivity there
+    m2 = make_model(docs, dictionary, K, st["X"], content=True, interactions=True, beta_index=st["aspect"], A=A, max_em_iter=1)
+    m2.beta, m2.sigma, m2.eta, m2.mu = st["beta"].copy(), st["sigma"].copy(), st["eta"] * (1.0 + 1e-13), st["mu"].copy()
+    m2._rec_reset()
+    m2.E_step()
+    s_nit = int(np.sum(np.asarray(m2.rec["nit"]) != r["nit"])); s_status = int(np.sum(np.asarray(m2.rec["status"]) != r["status"]))
+    s_eta = float(np.max(np.abs(m2.eta - m.eta)))
+    print(f"    reference vs reference(eta (1 + 1e-13)): nit differs in {s_nit}, status in {s_status}; eta max abs {s_eta:.3e}")
+    meta = dict(ref_self_nit=np.int32(s_nit), ref_self_status=np.int32(s_status), ref_self_eta=np.float64(s_eta))
+    for k in ("gpu_nit", "gpu_status", "gpu_eta", "em_iteration"):
+        if k in st.files:
+            meta[k] = st[k]
+    save("c5_long", indptr=indptr, indices=idx, counts=cnt, aspect=st["aspect"].astype(np.int32), X=st["X"], K=np.int32(K), V=np.int32(V), A=np.int32(A),
+         beta=st["beta"], sigma=st["sigma"], eta=st["eta"], mu=st["mu"], siginv=np.asarray(m.siginv), sigmaentropy=np.float64(m.sigmaentropy),
+         out_eta=m.eta.copy(), out_theta=m.theta.copy(), out_bound=np.float64(m.bound), out_bound_doc=np.asarray(m.rec["bound"]),
+         out_sigma_ss=sigma_ss.copy(), out_beta_ss_rowsum=beta_ss.sum(axis=-1), out_beta_ss_colsum=beta_ss.sum(axis=-2),
+         **{"out_" + k: v for k, v in r.items()},
+         ref_vs_oracle_nit=np.int32(d_nit), ref_vs_oracle_status=np.int32(d_status), ref_vs_oracle_eta=np.float64(d_eta),
+         ref_vs_oracle_eta_same_path=np.float64(d_eta_same), ref_vs_oracle_bound_rel=np.float64(d_bound), **meta)
+
+
+CASES = dict(long_c5=case_long_c5, mstep_modes=case_mstep_modes, toy_ctm=case_toy_ctm, heldout=case_heldout, functions=case_functions, edge=case_edge,
              content_a2=case_content_a2, c1_k10=case_c1_k10, k50_v10k=case_k50_v10k,
              wiki_k50=case_wiki_k50, wiki_k70=case_wiki_k70, k50_late=case_k50_late, spectral_c1=case_spectral_c1, k100_v5k=case_k100_v5k, content_k50=case_content_k50,
              spectral_wiki=case_spectral_wiki)

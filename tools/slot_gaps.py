@@ -5,6 +5,7 @@ concurrency; against the 4 documents x 256 CUs the registers allow, the rest is 
 (and the launch's tail) costs.     python tools/slot_gaps.py [docs V K [iteration]]"""
 import ctypes as C, os, sys
 os.environ["STM_DEBUG_PROF"] = "1"
+os.environ.setdefault("STM_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "strutopy_amd", "libstm_hip_testing.so"))   # debug switches: the -DSTM_TESTING build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from strutopy_amd import STM, _lib

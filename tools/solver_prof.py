@@ -3,6 +3,7 @@
 state machine / BFGS update, averaged over a 20k-document corpus at EM iteration 0 and 1."""
 import ctypes as C, os, sys
 os.environ["STM_DEBUG_PROF"] = "1"
+os.environ.setdefault("STM_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "strutopy_amd", "libstm_hip_testing.so"))   # debug switches: the -DSTM_TESTING build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from strutopy_amd import STM, _lib
