@@ -104,41 +104,58 @@ struct EpiParams {
 };
 
 // ---- the kernels of stm_mstep.h / stm_post_common.h as block bodies with explicit block coordinates ------------------------------
-__device__ __forceinline__ void moments_block(const double *X, const double *eta, int64_t N, int p, int n, double *part, int L, int bx, int gx) {
+// moments_kernel's block bx of gx -- the same sums, eight threads to a slot: the kernel's thread keeps eight partial sums t[0..7] over
+// sixteen documents at a time (t[j] takes documents d0 + 8 m + j in order, t[0] the remainder behind the last full sixteen) and combines
+// them in a fixed tree; here thread (slot, j) IS t[j] -- twelve dependent additions instead of ninety-eight at 100k documents -- and
+// the tree runs over the LDS.  Same operands, same order, same bits.
+__device__ __forceinline__ void moments_block(const double *X, const double *eta, int64_t N, int p, int n, double *part, int L, int bx, int gx,
+                                              double *sh /* [8][32] */) {
     const int64_t chunk = (N + gx - 1) / gx;
     const int64_t d0 = (int64_t)bx * chunk;
     const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
-    auto sum4 = [&](auto term) {
-        double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        int64_t d = d0;
-        for (; d + 15 < d1; d += 16) {
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = term(d + u);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t[u & 7] += v[u];
-        }
-        for (; d < d1; ++d) t[0] += term(d);
-        return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    };
-    for (int slot = threadIdx.x; slot < L; slot += 256) {
+    const int64_t len = d1 > d0 ? d1 - d0 : 0;
+    const int64_t full = len / 16 * 16;               // documents in full groups of sixteen
+    const int sl = threadIdx.x & 31, j = threadIdx.x >> 5;
+    auto strided = [&](auto term) {
         double t = 0.0;
-        int s = slot;
-        if (s == 0) {
-            t = (double)(d1 > d0 ? d1 - d0 : 0);
-        } else if ((s -= 1) < p) {
-            t = sum4([&](int64_t d) { return X[d * p + s]; });
-        } else if ((s -= p) < n) {
-            t = sum4([&](int64_t d) { return eta[d * n + s]; });
-        } else if ((s -= n) < p * p) {
-            const int a = s / p, b = s % p;
-            t = sum4([&](int64_t d) { return X[d * p + a] * X[d * p + b]; });
-        } else {
-            s -= p * p;
-            const int a = s / n, i = s % n;
-            t = sum4([&](int64_t d) { return X[d * p + a] * eta[d * n + i]; });
+        int64_t m = 0;
+        for (; m + 3 < full / 8; m += 4) {             // four of the thread's documents in flight
+            const double v0 = term(d0 + 8 * m + j), v1 = term(d0 + 8 * (m + 1) + j), v2 = term(d0 + 8 * (m + 2) + j), v3 = term(d0 + 8 * (m + 3) + j);
+            t += v0; t += v1; t += v2; t += v3;
         }
-        part[(size_t)bx * L + slot] = t;
+        for (; m < full / 8; ++m) t += term(d0 + 8 * m + j);
+        if (j == 0)
+            for (int64_t d = d0 + full; d < d1; ++d) t += term(d);
+        return t;
+    };
+    for (int s0 = 0; s0 < L; s0 += 32) {
+        const int slot = s0 + sl;
+        double t = 0.0;
+        if (slot < L) {
+            int s = slot;
+            if (s == 0) {
+                t = j == 0 ? (double)len : 0.0;
+            } else if ((s -= 1) < p) {
+                t = strided([&](int64_t d) { return X[d * p + s]; });
+            } else if ((s -= p) < n) {
+                t = strided([&](int64_t d) { return eta[d * n + s]; });
+            } else if ((s -= n) < p * p) {
+                const int a = s / p, b = s % p;
+                t = strided([&](int64_t d) { return X[d * p + a] * X[d * p + b]; });
+            } else {
+                s -= p * p;
+                const int a = s / n, i = s % n;
+                t = strided([&](int64_t d) { return X[d * p + a] * eta[d * n + i]; });
+            }
+        }
+        __syncthreads();
+        sh[j * 32 + sl] = t;
+        __syncthreads();
+        if (j == 0 && slot < L) {
+            const double r = slot == 0 ? sh[sl]
+                                       : ((sh[sl] + sh[32 + sl]) + (sh[64 + sl] + sh[96 + sl])) + ((sh[128 + sl] + sh[160 + sl]) + (sh[192 + sl] + sh[224 + sl]));
+            part[(size_t)bx * L + slot] = r;
+        }
     }
 }
 
@@ -160,26 +177,31 @@ __device__ __forceinline__ void covariance_block(const double *eta, const double
     const int64_t chunk = (N + gx - 1) / gx;
     const int64_t d0 = (int64_t)bx * chunk;
     const int64_t d1 = d0 + chunk < N ? d0 + chunk : N;
+    // (the next tile's global loads are issued behind the current tile's LDS stores and land while it is multiplied: a block's four
+    // tiles at 100k documents were four exposed round trips to memory)
+    double v[PER];
+    auto fetch = [&](int64_t base) __attribute__((always_inline)) {
+        const int cnt = (int)((d1 - base) < COV_TD ? (d1 - base) : COV_TD);
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int q = threadIdx.x + 256 * it, dd = q / W, c = q & (W - 1);
+            const int i = ONE ? c : (c < 64 ? 64 * bz : 64 * by - 64) + c;
+            const bool in = dd < cnt && i < n;
+            const int64_t at = in ? (base + dd) * n + i : 0;
+            const double e = eta[at], m = mu ? mu[at] : 0.0;
+            v[it] = in ? (mu ? e - m : e) : 0.0;
+        }
+    };
+    if (d0 < d1) fetch(d0);
     for (int64_t base = d0; base < d1; base += COV_TD) {
         const int cnt = (int)((d1 - base) < COV_TD ? (d1 - base) : COV_TD);
-        {
-            double v[PER];
 #pragma unroll
-            for (int it = 0; it < PER; ++it) {
-                const int q = threadIdx.x + 256 * it, dd = q / W, c = q & (W - 1);
-                const int i = ONE ? c : (c < 64 ? 64 * bz : 64 * by - 64) + c;
-                const bool in = dd < cnt && i < n;
-                const int64_t at = in ? (base + dd) * n + i : 0;
-                const double e = eta[at], m = mu ? mu[at] : 0.0;
-                v[it] = in ? (mu ? e - m : e) : 0.0;
-            }
-#pragma unroll
-            for (int it = 0; it < PER; ++it) {
-                const int q = threadIdx.x + 256 * it;
-                tile[(q / W) * LDW + (q & (W - 1))] = v[it];
-            }
+        for (int it = 0; it < PER; ++it) {
+            const int q = threadIdx.x + 256 * it;
+            tile[(q / W) * LDW + (q & (W - 1))] = v[it];
         }
         __syncthreads();
+        if (base + COV_TD < d1) fetch(base + COV_TD);
         for (int dd = 0; dd < cnt; ++dd) {
             const double2 *row = reinterpret_cast<const double2 *>(tile + dd * LDW);
             const double2 a01 = row[ia >> 1], a23 = row[(ia >> 1) + 1], b01 = row[ja >> 1], b23 = row[(ja >> 1) + 1];
@@ -187,7 +209,7 @@ __device__ __forceinline__ void covariance_block(const double *eta, const double
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+                for (int vv = 0; vv < 4; ++vv) acc[u][vv] = fma(a[u], b[vv], acc[u][vv]);
         }
         __syncthreads();
     }
@@ -249,7 +271,7 @@ __global__ __launch_bounds__(256) void epilogue_a_kernel(EpiParams ep) {
     }
     id -= ep.nb_cov;
     if (id < ep.nb_mom) {
-        moments_block(ep.X, ep.eta, ep.N, ep.p, ep.n, ep.mom_part, ep.Lr, id, ep.nb_mom);
+        moments_block(ep.X, ep.eta, ep.N, ep.p, ep.n, ep.mom_part, ep.Lr, id, ep.nb_mom, smem);
         return;
     }
     id -= ep.nb_mom;
@@ -374,20 +396,41 @@ __global__ __launch_bounds__(256) void mstep_tail_a_kernel(TailParams tp) {
     }
     const int64_t tot = tp.N * tp.n;
     const int n = tp.n, p = tp.p;
-    auto one = [&](int64_t q, int64_t d, int i) __attribute__((always_inline)) {
-        if (!tp.X) { tp.mu[q] = coef[i]; return; }
-        double t = 0.0;
-        for (int a = 0; a < p; ++a) t += tp.X[d * p + a] * coef[(size_t)i * p + a];
-        tp.mu[q] = t;
-    };
-    if (tot < ((int64_t)1 << 32)) {   // (a 64-bit division per element is most of the kernel otherwise)
-        const unsigned un = (unsigned)n, step = (unsigned)tp.nb_mu * 256u;
-        for (uint64_t q = (uint64_t)id * 256 + threadIdx.x; q < (uint64_t)tot; q += step) {
-            const unsigned d = (unsigned)q / un;
-            one((int64_t)q, d, (int)((unsigned)q - d * un));
+    // four elements per thread and round: their covariate loads fly together (one element at a time is a chain of dependent round
+    // trips to memory, nine of them per thread at 100k documents)
+    auto four = [&](const int64_t (&q)[4], const int64_t (&d)[4], const int (&i)[4], int cnt) __attribute__((always_inline)) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!tp.X) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = coef[i[u]];
+        } else {
+            for (int a = 0; a < p; ++a) {
+                double xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = tp.X[d[u] * p + a];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] += xv[u] * coef[(size_t)i[u] * p + a];
+            }
         }
-    } else {
-        for (int64_t q = (int64_t)id * 256 + threadIdx.x; q < tot; q += (int64_t)tp.nb_mu * 256) one(q, q / n, (int)(q % n));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < cnt) tp.mu[q[u]] = t[u];
+    };
+    const int64_t step = (int64_t)tp.nb_mu * 256;
+    const bool small = tot < ((int64_t)1 << 32);   // (a 64-bit division per element is most of the arithmetic otherwise)
+    for (int64_t q0 = (int64_t)id * 256 + threadIdx.x; q0 < tot; q0 += 4 * step) {
+        int64_t q[4], d[4];
+        int i[4], cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t qq = q0 + u * step;
+            const bool in = qq < tot;
+            cnt += in ? 1 : 0;
+            q[u] = in ? qq : q0;                  // (beyond the end: the first element again, computed and not stored)
+            if (small) { const unsigned du = (unsigned)q[u] / (unsigned)n; d[u] = du; i[u] = (int)((unsigned)q[u] - du * (unsigned)n); }
+            else { d[u] = q[u] / n; i[u] = (int)(q[u] % n); }
+        }
+        four(q, d, i, cnt);
     }
 }
 
@@ -428,11 +471,20 @@ __global__ __launch_bounds__(256) void mstep_tail_b_kernel(TailParams tp) {
     const int v0 = blockIdx.x * tp.wpb, v1 = v0 + tp.wpb < tp.V ? v0 + tp.wpb : tp.V;
     const int cnt = (v1 - v0) * K;
     const size_t base = (size_t)v0 * K;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
-        const double r = rs[e % K];
-        const double v = (r != 0.0) ? tp.bssT[base + e] / r : 0.0;
-        tp.betaT[base + e] = v;
-        rows[e] = v;
+    for (int e0 = threadIdx.x; e0 < cnt; e0 += 4 * 256) {   // (four loads in flight: one at a time is a chain of round trips to memory)
+        double bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = tp.bssT[base + (e0 + 256 * u < cnt ? e0 + 256 * u : e0)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < cnt) {
+                const double r = rs[e % K];
+                const double v = (r != 0.0) ? bv[u] / r : 0.0;
+                tp.betaT[base + e] = v;
+                rows[e] = v;
+            }
+        }
     }
     __syncthreads();
     for (int w = threadIdx.x; w < v1 - v0; w += 256) {

@@ -792,8 +792,14 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
         // DMA form: the count of the lane's register word waits in the LDS, behind the BFGS matrix, where the staging rows of the set-up
         // were (both waves are past them: the barrier above) -- an evaluation uses it once, at its very end, and two registers held
         // through the whole document for that were what the allocator spilled (read back from scratch in front of every wave sum)
+        // (its address is formed anew at every use: held in a register it was spilled in c0's place)
         if constexpr (DMA) Hs[(size_t)n * n + tid] = c0;
-#define STM_C0 (DMA ? Hs[(size_t)n * n + tid] : c0)
+        auto c0_lds = [&]() __attribute__((always_inline)) -> double {
+            unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // the lane, from the hardware (two instructions;
+            asm volatile("" : "+v"(l));                                                        //  the thread index itself sits in scratch by now)
+            return Hs[(size_t)n * n + WAVE * wv + l];
+        };
+#define STM_C0 (DMA ? c0_lds() : c0)
 #else
 #define STM_C0 c0
 #endif

@@ -9,3 +9,4 @@ echo "== small"; timeout 200 python bench.py --docs 12500 --steps 20 --warmup 5 
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], {k:v.get('avg_launch_ms') for k,v in d['roofline']['kernels'].items()})"
 echo "== default"; for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], {k:v.get('avg_launch_ms') for k,v in d['roofline']['kernels'].items()})"; done
+echo "== solver cycles"; timeout 300 python tools/solver_prof.py 100000 10000 50 8 7 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | head -1 | cut -c1-330
