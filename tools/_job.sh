@@ -1,7 +1,6 @@
 export TMPDIR=/tmp
-echo "== r05 persistent"; STM_LIB_PATH=$PWD/strutopy_amd/libstm_r05.so timeout 300 python tools/solver_prof.py 100000 10000 50 8 7 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | head -3 | cut -c1-330
-echo "== nopersist form, one workgroup per document"; STM_SOLVER_PERSIST=0 STM_LIB_PATH=$PWD/strutopy_amd/libstm_nopersist.so timeout 300 python tools/solver_prof.py 100000 10000 50 8 7 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | head -3 | cut -c1-330
-echo "== r05 lib, STM_SOLVER_PERSIST=0"; STM_SOLVER_PERSIST=0 STM_LIB_PATH=$PWD/strutopy_amd/libstm_r05.so timeout 300 python tools/solver_prof.py 100000 10000 50 8 7 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | head -3 | cut -c1-330
-echo "== testing lib (c0 in LDS)"; timeout 300 python tools/solver_prof.py 100000 10000 50 8 7 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | head -3 | cut -c1-330
-echo "== bitcmp"; timeout 600 python tools/bitcmp.py strutopy_amd/libstm_r05.so strutopy_amd/libstm_hip.so 100000 20 | tail -5
-echo "== k512 + new tests"; timeout 900 python -m pytest tests -m gpu -q -x -k "more_than_128 or run_to_run or exchange" 2>&1 | grep -E "passed|failed|rror" | tail -3
+bash tools/profile_r06.sh r06 > gpurun_out/r06_profile.log 2>&1
+echo "== c4, three documents per CU in the post step (what a padded matrix would cost)"
+for w in 0 3; do STM_POST_MAX_WG_PER_CU=$w timeout 600 python bench.py --config c4 --steps 8 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('STM_POST_MAX_WG_PER_CU=$w', round(d['value']), round(d['ms_per_step'],3), {k:round(v.get('avg_launch_ms'),3) for k,v in d['roofline']['kernels'].items()})"; done
+tail -5 gpurun_out/r06_profile.log

@@ -20,7 +20,7 @@ def kname(r):
     n = r["Kernel_Name"]
     if "solver_kernel" in n:
         return "solver"
-    if "post_big_kernel" in n or "post_kernel" in n or "post_big2_kernel" in n:
+    if "post_any_kernel" in n or "post_kernel" in n or "post_big2_kernel" in n:
         return "post"
     if "beta_ss_part" in n or "beta_ss_reduce_kernel" in n:
         return "betass"      # the word-major beta_ss pass behind the K <= 64 post kernel (round 3)

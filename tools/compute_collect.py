@@ -27,7 +27,7 @@ CLOCK_GHZ, SIMDS = 2.4, 1024
 def kname(n):
     if "solver_kernel" in n:
         return "solver"
-    if "post_big_kernel" in n or "post_kernel" in n or "post_big2_kernel" in n:
+    if "post_any_kernel" in n or "post_kernel" in n or "post_big2_kernel" in n:
         return "post"
     if "beta_ss_part" in n or "beta_ss_reduce_kernel" in n:
         return "betass"

@@ -23,7 +23,7 @@ WARM = len(sys.argv) > 3 and sys.argv[3] == "warm"
 fired = [0, 0]
 bad = 0
 for case in range(n_cases):
-    K = int(rng.choice([2, 3, 5, 10, 16, 17, 18, 33, 34, 49, 50, 51, 64, 65, 66, 70, 80, 81, 97, 100, 112, 113, 128, 129, 150, 200, 257]))   # (65..80, 81..112: the two tile pitches of post_big2_kernel; 113+: post_big_kernel; 129+: the general forms, stm_post_any.h)
+    K = int(rng.choice([2, 3, 5, 10, 16, 17, 18, 33, 34, 49, 50, 51, 64, 65, 66, 70, 80, 81, 97, 100, 112, 113, 128, 129, 150, 200, 257]))   # (65..80, 81..112: the two tile pitches of post_big2_kernel; 113+: post_any_kernel; 129+: the general forms, stm_post_any.h)
     V = int(rng.integers(3000, 9000)) if LONG else int(rng.integers(max(K, 40), 4000))
     N = int(rng.integers(1, 80))
     maxlen = int(rng.choice([3, 20, 70, 140, 200, 400, min(V, 1500)]))

@@ -53,7 +53,7 @@ for it in range(ITS):
         else:   # K <= 64: no T <- b phase since round 4 (stm_post.h)
             print("   post tile phases cycles/doc: fetch wait %.0f, sums %.0f, b b^T + lane = topic pass %.0f, round end %.0f" % tuple(out[:, 24:28].mean(0)))
     print("   post inverse phases cycles/doc: diag blocks %.0f, MFMA blocks %.0f, remainder row %.0f, pre %.0f" % tuple(out[:, 28:32].mean(0)))
-    if KK > 64:   # post_big_kernel reuses the last two slots (and slot 23) for its Cholesky
+    if KK > 64:   # post_any_kernel reuses the last two slots (and slot 23) for its Cholesky
         print("   post_big Cholesky cycles/doc: block column updates %.0f, panel loads %.0f, panels %.0f" % (out[:, 30].mean(), out[:, 23].mean(), out[:, 31].mean()))
     for i, nm in enumerate(names):
         c, v = (out[:, 8 + i] & ((1 << 40) - 1)).mean(), (out[:, 8 + i] >> 40).mean()

@@ -25,7 +25,7 @@ for r in rows:
         if cur:
             its.append(cur)
         cur, seen_post = [], False
-    if "post_kernel" in n or "post_big_kernel" in n or "post_big2_kernel" in n:
+    if "post_kernel" in n or "post_any_kernel" in n or "post_big2_kernel" in n:
         seen_post = True
     cur.append(r)
 its.append(cur)

@@ -36,7 +36,7 @@ def per_iteration(path):
     for d, (k, v) in by.items():
         if "solver_kernel" in k and seen_post:
             its.append(cur); cur, seen_post = collections.defaultdict(float), False
-        if "post_kernel" in k or "post_big_kernel" in k or "post_big2_kernel" in k:
+        if "post_kernel" in k or "post_any_kernel" in k or "post_big2_kernel" in k:
             seen_post = True
         cur[k] += v
         ndisp[k] += 1
