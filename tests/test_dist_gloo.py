@@ -129,7 +129,7 @@ def test_two_rank_fit_equals_single_process(case, model_type, group, xkind, tmp_
                 assert np.array_equal(a, b)         # the covariate rows, in corpus order
             elif f in ("eta_hat.npy", "theta_hat.npy"):
                 # per document: two shards add beta_ss in another order than one process does (1e-16), and once in a while a
-                # document's last line search accepts one step more or less for it ("noise-level accept /
+                # document's last line search accepts one step more or less for it (DESIGN.md sections 2 and 7; profiles/HISTORY.md section 9, "noise-level accept /
                 # reject") -- such a row must show it in the solver's own counts; every other row holds the tight tolerance
                 rows = ~np.all(np.isclose(a, b, rtol=1e-7, atol=1e-8), axis=1)
                 assert rows.sum() <= 2 and not np.any(rows & ~searched) and np.allclose(a, b, rtol=0, atol=1e-3), (f, int(rows.sum()))

@@ -312,7 +312,7 @@ def test_solver_variants_agree_with_the_oracle(oracle, monkeypatch, mode):
 def test_exactly_singular_hessian_after_make_pd(oracle):
     """K = 3: make_pd turns the 2 x 2 Hessian of some documents into [[|o|, o], [o, |o|]], exactly singular; the sign of the second
     pivot (like the sign of the smallest eigenvalue the reference tests, stm.py:1017) is rounding noise there.  Oracle and kernels
-    count a pivot within 32 ulp of the cancelled diagonal as failed, so both take the + 1e-5 branch and nu
+    count a pivot within 32 ulp of the cancelled diagonal as failed (profiles/HISTORY.md section 9), so both take the + 1e-5 branch and nu
     stays finite.  Inputs: a case found by tools/fuzz_parity.py (58 documents, three beta levels, counts up to 1000)."""
     from strutopy_amd.engine import estep_host
     g = load_golden("k3_singular_inputs")

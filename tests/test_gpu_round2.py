@@ -712,7 +712,7 @@ def test_integration_stub_runs_against_a_reference_shaped_object():
 def test_long_run_regime_of_config5_is_within_the_oracles_own_sensitivity(oracle, monkeypatch):
     """Config 5's shape (content covariate, A = 2 levels of beta) scaled to 4000 documents and driven on the device until the
     fit is in the long-run regime -- mean scipy `nit` >= 8: every document takes about ten BFGS iterations, and ten
-    iterations amplify a last-bit difference into one accepted step more or less.  One teacher-forced
+    iterations amplify a last-bit difference into one accepted step more or less (DESIGN.md sections 2 and 7; profiles/HISTORY.md section 9).  One teacher-forced
     E-step from that state, four ways:
       (i)  the HIP path with and without its outcome-preserving line-search cuts (STM_DEBUG_FLAGS = 0 / 6) -- identical
            status / nit / eta, bit for bit: the cuts are not what moves a document there;

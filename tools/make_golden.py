@@ -644,7 +644,7 @@ def case_long_c5():
     The imported reference is TEACHER-FORCED on that state for ONE E-step; per document its status / nit / nfev / eta / bound are the
     golden.  The oracle's run on the same state is compared here and the counts of documents where it differs from the reference are
     stored as metadata (`ref_vs_oracle_*`): ten BFGS iterations amplify a last-bit difference into one accepted step more or less
-    (DESIGN section 9), so the tests' bar for the HIP path is the oracle's own distance from the reference, not zero.
+    (DESIGN.md sections 2 and 7; profiles/HISTORY.md section 9), so the tests' bar for the HIP path is the oracle's own distance from the reference, not zero.
     Without the state file the inputs are taken from the existing golden (re-generation on a new scipy)."""
     src = os.path.join(REPO, "gpurun_out", "c5_long_state.npz")
     if not os.path.exists(src):

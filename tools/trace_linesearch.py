@@ -7,9 +7,9 @@ with scipy itself (scalar_search_wolfe1 / scalar_search_wolfe2 driven by a BFGS 
 
 Per (search index k, success) it prints how many searches there are, how many evaluations scipy spends, and how many of them the
 moment test of stm_solver.h (S_MOMENTS; restated in tests/test_moment_pass_math.py for k = 0) proves dead -- at the start of the
-search and after three DCSRCH evaluations (the general interval [s_x, max(b, 5 s_x, L)]).  A proof for a search
+search and after three DCSRCH evaluations (the general interval [s_x, max(b, 5 s_x, L)], profiles/HISTORY.md 4.1).  A proof for a search
 that SUCCEEDS would be a soundness bug: the tool exits with status 1 if it ever sees one.  This is the evidence behind the
-percentages quoted in DESIGN.md; it is not part of the test suite (a minute per 400 documents)."""
+percentages quoted in profiles/HISTORY.md; it is not part of the test suite (a minute per 400 documents)."""
 import os, sys, warnings
 import numpy as np
 from scipy.optimize._linesearch import scalar_search_wolfe1, scalar_search_wolfe2
