@@ -400,3 +400,29 @@ def test_product_never_touches_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "libstm_oracle" not in txt and "stm_oracle" not in txt, f
+
+
+def test_lasso_from_moments_is_sklearns_lasso():
+    """mode="lasso" (stm.py:677-681) from the centred moments alone: strutopy_amd.stm.lasso_from_moments (coordinate descent on the
+    Gram matrix -- sklearn's enet_coordinate_descent_gram restated, all targets side by side) against sklearn.linear_model.Lasso
+    (alpha = 1, fit_intercept = True: what the reference calls) on one-hot and dense designs, shrunk-to-zero and dense solutions."""
+    import sklearn.linear_model as lm
+    from strutopy_amd.stm import lasso_from_moments
+    rng = np.random.default_rng(0)
+    for trial in range(6):
+        N, n = 400 + 50 * trial, 9
+        if trial < 3:
+            X = np.eye(3)[rng.integers(0, 3, N)]                       # a three-level covariate, one-hot (singular centred Gram matrix)
+        else:
+            X = rng.normal(size=(N, 5)) * 3.0
+        G = rng.normal(size=(X.shape[1], n)) * (4.0 if trial % 2 else 1.2)
+        eta = X @ G + rng.normal(size=(N, n))
+        want = lm.Lasso(alpha=1, fit_intercept=True).fit(X, eta).coef_
+        Xc, yc = X - X.mean(0), eta - eta.mean(0)
+        got = lasso_from_moments(Xc.T @ Xc, Xc.T @ yc, np.sum(yc * yc, axis=0), N)
+        assert got.shape == want.shape and np.allclose(got, want, rtol=1e-9, atol=1e-10), trial
+        # ... and from the raw sums a sharded fit all-reduces (what _em_iteration_resident forms them from)
+        xb, eb = X.mean(0), eta.mean(0)
+        got2 = lasso_from_moments(X.T @ X - N * np.outer(xb, xb), X.T @ eta - N * np.outer(xb, eb), np.sum(eta * eta, axis=0) - N * eb * eb, N)
+        assert np.allclose(got2, want, rtol=1e-7, atol=1e-9), trial
+    assert np.count_nonzero(want) > 0

@@ -1,6 +1,6 @@
 export TMPDIR=/tmp
-bash tools/profile_r06.sh r06 > gpurun_out/r06_profile.log 2>&1
-echo "== c4, three documents per CU in the post step (what a padded matrix would cost)"
-for w in 0 3; do STM_POST_MAX_WG_PER_CU=$w timeout 600 python bench.py --config c4 --steps 8 --warmup 2 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('STM_POST_MAX_WG_PER_CU=$w', round(d['value']), round(d['ms_per_step'],3), {k:round(v.get('avg_launch_ms'),3) for k,v in d['roofline']['kernels'].items()})"; done
-tail -5 gpurun_out/r06_profile.log
+echo "== fuzz_parity 160 cases seed 606"; timeout 1500 python tools/fuzz_parity.py 160 606 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6
+echo "== fuzz_parity warm 100 seed 607"; timeout 1500 python tools/fuzz_parity.py 100 607 warm 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6
+echo "== fuzz_parity long 30 seed 608"; timeout 1500 python tools/fuzz_parity.py 30 608 long 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6
+echo "== fuzz_em 80 seed 61"; timeout 1500 python tools/fuzz_em.py 80 61 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -6
+for c in tools/cases/*.npz; do echo "== $c"; timeout 300 python tools/fuzz_case.py $c 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | grep "STM_DEBUG_FLAGS" ; done

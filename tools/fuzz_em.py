@@ -13,7 +13,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 bad = 0
 for case in range(n_cases):
-    K = int(rng.choice([2, 3, 5, 10, 17, 33, 50, 64, 65, 81, 100, 112, 120]))
+    K = int(rng.choice([2, 3, 5, 10, 17, 33, 50, 64, 65, 81, 100, 112, 113, 120, 128]))
     V = int(rng.integers(max(K, 60), 1500)); N = int(rng.integers(8, 300))
     lens = rng.integers(1, min(V, 120) + 1, size=N)
     docs = [np.sort(rng.choice(V, int(L), replace=False)) for L in lens]
@@ -22,7 +22,7 @@ for case in range(n_cases):
     counts = rng.integers(1, 6, size=len(indices)).astype(np.float64)
     c = PackedCorpus(indptr, indices, counts, V)
     model_type = str(rng.choice(["STM", "STM", "CTM"]))
-    mode = str(rng.choice(["ols", "ols", "ridge"]))
+    mode = str(rng.choice(["ols", "ols", "ridge", "lasso"]))
     p = int(rng.integers(1, 4))
     X = rng.integers(0, 2, size=(N, p)).astype(np.float64)
     content = bool(rng.random() < 0.25)
