@@ -883,16 +883,22 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
         // of b b^T rides on the VALU instead of a padded block (post_kernel)
         const bool rem = n > 16 && n % 16 == 1 && h->sw.post_rem;
         const int nb = rem ? n / 16 : (n + 15) / 16;
+        // the DBG = true instantiations (per-document dumps, cycle counters, LDS poisoning) exist in the -DSTM_TESTING build only
+#ifdef STM_TESTING
         const bool dbg = h->d_nu != nullptr || h->d_prof != nullptr || post_debug != 0;
+#define STM_DBG_PICK(KERNEL_DBG, KERNEL) (dbg ? (KERNEL_DBG) : (KERNEL))
+#else
+#define STM_DBG_PICK(KERNEL_DBG, KERNEL) (KERNEL)
+#endif
         PostFn pf;
         if (rem) {
-            pf = dbg ? (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, true> : stm::post_kernel<3, 1, POST_WPE, true>)
-                     : (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, false> : stm::post_kernel<3, 1, POST_WPE, false>);
+            pf = STM_DBG_PICK((nb == 1 ? stm::post_kernel<1, 1, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, true> : stm::post_kernel<3, 1, POST_WPE, true>),
+                              (nb == 1 ? stm::post_kernel<1, 1, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 1, POST_WPE, false> : stm::post_kernel<3, 1, POST_WPE, false>));
         } else {
-            pf = dbg ? (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, true>
-                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, true> : stm::post_kernel<4, 0, 2, true>)
-                     : (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, false>
-                        : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>);
+            pf = STM_DBG_PICK((nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, true> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, true>
+                               : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, true> : stm::post_kernel<4, 0, 2, true>),
+                              (nb <= 1 ? stm::post_kernel<1, 0, POST_WPE, false> : nb == 2 ? stm::post_kernel<2, 0, POST_WPE, false>
+                               : nb == 3 ? stm::post_kernel<3, 0, POST_WPE, false> : stm::post_kernel<4, 0, 2, false>));
         }
         const bool big2 = h->big2;                  // two waves per document (stm_post_big2.h)
         const bool any = h->any;                    // any K: one workgroup per document, everything in HBM scratch (stm_post_any.h)
@@ -902,11 +908,12 @@ static int estep_plan(stm_handle *h, bool em_stage, EstepPlan &pl) {
         const int pc2 = stm::post2_pc(K);
         const int nwv2 = h->sw.post_big2_waves == 4 ? 4 : 2;   // waves per document (stm_post_big2.h)
         if (big2) {
-#define STM_PB2(NBV, PCV) (nwv2 == 4 ? (dbg ? stm::post_big2_kernel<NBV, PCV, true, 4> : stm::post_big2_kernel<NBV, PCV, false, 4>) \
-                                     : (dbg ? stm::post_big2_kernel<NBV, PCV, true, 2> : stm::post_big2_kernel<NBV, PCV, false, 2>))
+#define STM_PB2(NBV, PCV) (nwv2 == 4 ? STM_DBG_PICK((stm::post_big2_kernel<NBV, PCV, true, 4>), (stm::post_big2_kernel<NBV, PCV, false, 4>)) \
+                                     : STM_DBG_PICK((stm::post_big2_kernel<NBV, PCV, true, 2>), (stm::post_big2_kernel<NBV, PCV, false, 2>)))
             if (pc2 == 40) pf2 = nbb <= 4 ? STM_PB2(4, 40) : STM_PB2(5, 40);
             else pf2 = nbb <= 5 ? STM_PB2(5, 56) : nbb == 6 ? STM_PB2(6, 56) : STM_PB2(7, 56);
 #undef STM_PB2
+#undef STM_DBG_PICK
         }
         pfn = any ? (h->wm ? (PostFn)stm::post_any_kernel<true> : (PostFn)stm::post_any_kernel<false>) : big2 ? pf2 : pf;
         wg_threads = any ? (unsigned)stm::ANY_BS : big2 ? 64u * (unsigned)nwv2 : 64u;

@@ -75,6 +75,14 @@
 #define STM_MOM_GROUP 8    // ... of the moment pass (three broadcast vectors, six sums)
 #endif
 
+// the per-document cycle counters (tools/solver_prof.py) exist in the -DSTM_TESTING build only: in the product kernel their clock reads and
+// running totals are compiled out (31 spilled SGPRs less in the two-wave K = 50 form)
+#ifdef STM_TESTING
+#define STM_PROF(P) ((P).prof)
+#else
+#define STM_PROF(P) ((long long *)nullptr)
+#endif
+
 namespace stm {
 
 // LDS hand-off between lanes of ONE wave: the LDS executes a wave's operations in order, so only
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             for (int q = tid; q < KMAX + 1; q += WAVE * NW) { sv[q] = __builtin_nan(""); sw[q] = __builtin_nan(""); se[q] = __builtin_nan(""); }
             __syncthreads();
         }
-        const long long t_begin = P.prof ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
+        const long long t_begin = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;   // set-up (gather, g0) counts as init
         // the document's header: one 16-byte scalar load (order -> indptr would be two dependent round trips before the first index load)
         int64_t doc, p0;
         int Nd;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             Nd = (int)(scalar_load(P.indptr + doc + 1) - p0);
         }
         const int NdL = (Nd > VREG && wv == NW - 1) ? Nd - VREG : 0;  // words in the slab (<= ld): the last wave's
-        if (P.prof && tid == 0) P.prof[doc * PROF_SLOTS + 39] = (long long)wall_clock64();   // (100 MHz, the same on every XCD: the XCDs' shader clocks are not aligned; tools/slot_gaps.py)
+        if (STM_PROF(P) && tid == 0) STM_PROF(P)[doc * PROF_SLOTS + 39] = (long long)wall_clock64();   // (100 MHz, the same on every XCD: the XCDs' shader clocks are not aligned; tools/slot_gaps.py)
         const int asp = P.aspect ? scalar_load(P.aspect + doc) : 0;
         const double *bT = P.betaT + (size_t)asp * (size_t)P.V * K;
 
@@ -657,8 +665,8 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                     if (lane == k) g0[0] += t;
                 }
             }
-            t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-            if (P.prof && wv == 1 && lane == 0) P.prof[doc * PROF_SLOTS + 7] = t_g1 - t_begin;
+            t_g1 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
+            if (STM_PROF(P) && wv == 1 && lane == 0) STM_PROF(P)[doc * PROF_SLOTS + 7] = t_g1 - t_begin;
         }
         if constexpr (!DMA) {
         if (KREG > 0) {
@@ -762,8 +770,8 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             wrow[vv] = c / colsum;
             csum += c;
         }
-        t_g1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-        if (P.prof && NW == 2 && wv == 1 && lane == 0) P.prof[doc * PROF_SLOTS + 7] = t_g1 - t_begin;   // wave 1: register rows + slab
+        t_g1 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
+        if (STM_PROF(P) && NW == 2 && wv == 1 && lane == 0) STM_PROF(P)[doc * PROF_SLOTS + 7] = t_g1 - t_begin;   // wave 1: register rows + slab
         }   // !DMA
         // se[k] stays 0 for k >= K (the register pass is unrolled to KREG)
         if (wv == 0) {
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             STM_WAVE_SYNC();
         }
 
-        const long long t_g2 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+        const long long t_g2 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
         // ---- DIRECT: one LDS tile of TWS rows, fetched from betaT for every pass over the document, one tile ahead of its use.
         // Lane l loads components 2 l and 2 l + 1 of a row: ONE 16-byte load per row and lane (K <= 128: the whole row in one
         // instruction, scalar base + 32-bit lane offset -- a level of beta stays below 4 GiB, stm_set_topics) and one 16-byte LDS
@@ -1018,8 +1026,8 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             }
         }
 
-        const long long t_g3 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
-        if (P.prof && lane == 0 && wv == 0) { P.prof[doc * PROF_SLOTS + 4] = t_g1 - t_begin; P.prof[doc * PROF_SLOTS + 5] = t_g2 - t_g1; P.prof[doc * PROF_SLOTS + 6] = t_g3 - t_g2; }
+        const long long t_g3 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
+        if (STM_PROF(P) && lane == 0 && wv == 0) { STM_PROF(P)[doc * PROF_SLOTS + 4] = t_g1 - t_begin; STM_PROF(P)[doc * PROF_SLOTS + 5] = t_g2 - t_g1; STM_PROF(P)[doc * PROF_SLOTS + 6] = t_g3 - t_g2; }
         long long t_init = 0, t_eval = 0, t_sm = 0, t_upd = 0;
         int nfev = 0, njev = 0;
         double *svx = (NW == 2 && wv == 1) ? svb : sv;  // this wave's private broadcast vector
@@ -1612,7 +1620,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                 const int k0 = dq * kq2, k1 = (dq + 1) * kq2 < (KP >> 1) ? (dq + 1) * kq2 : (KP >> 1);
 #ifdef STM_SWEEP_PROF   // a build for tools/solver_prof.py: wait + store / fetch issue / (1) / (2) / (3) into profile slots 40-44
                 long long tsw[5] = {0, 0, 0, 0, 0};
-#define STM_SWEEP_MARK(q, ...) if (P.prof) { __VA_ARGS__; const long long cy = __builtin_readcyclecounter(); tsw[q] += cy - cy0; cy0 = cy; }
+#define STM_SWEEP_MARK(q, ...) if (STM_PROF(P)) { __VA_ARGS__; const long long cy = __builtin_readcyclecounter(); tsw[q] += cy - cy0; cy0 = cy; }
 #else
 #define STM_SWEEP_MARK(q, ...)
 #endif
@@ -1620,7 +1628,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                 for (int t0 = 0; t0 < NdL; t0 += TWS) {
                     const int nw = NdL - t0 < TWS ? NdL - t0 : TWS;
 #ifdef STM_SWEEP_PROF
-                    long long cy0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+                    long long cy0 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
 #endif
                     tile_store(nw);
                     STM_WAVE_SYNC();
@@ -1653,7 +1661,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                     STM_SWEEP_MARK(4, pin(va[0]))
                 }
 #ifdef STM_SWEEP_PROF
-                if (P.prof && lane == 0) for (int q = 0; q < 5; ++q) P.prof[doc * PROF_SLOTS + 40 + q] = tsw[q];
+                if (STM_PROF(P) && lane == 0) for (int q = 0; q < 5; ++q) STM_PROF(P)[doc * PROF_SLOTS + 40 + q] = tsw[q];
 #endif
 #pragma unroll
                 for (int r = 0; r < VPL; ++r) {
@@ -1800,11 +1808,11 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             // -DSTM_EVAL_PROF: where one evaluation's cycles go on wave 0 (profile slots 40..44, accumulated in memory).  Not in
             // the shipped build: the clock reads cost ten spilled SGPRs around every evaluation.
 #ifdef STM_EVAL_PROF
-            long long tc = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            long long tc = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
             auto lap = [&](int slot) __attribute__((always_inline)) {
-                if (P.prof) {
+                if (STM_PROF(P)) {
                     const long long now = (long long)__builtin_readcyclecounter();
-                    if (lane == 0) P.prof[doc * PROF_SLOTS + slot] += now - tc;
+                    if (lane == 0) STM_PROF(P)[doc * PROF_SLOTS + slot] += now - tc;
                     tc = now;
                 }
             };
@@ -2027,10 +2035,10 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
         if (P.debug_flags & 1) st = S_FINISH;
         const bool cuts = !(P.debug_flags & 2), reuse = !(P.debug_flags & 4), mproof = !(P.debug_flags & 16);
         long guard = 0;
-        if (P.prof) t_init = (long long)__builtin_readcyclecounter() - t_begin;
+        if (STM_PROF(P)) t_init = (long long)__builtin_readcyclecounter() - t_begin;
         while (st != S_FINISH) {
             if (++guard > 400000L) { status = 1000 + st; break; }
-            const long long tq0 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            const long long tq0 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
             if (MOM && NW == 1 && want_mom) {   // one-wave forms: the moment pass requested by S_OUTER_TOP (operands in se / sv / sw)
                 double d1, d2;
                 moments_words(d1, d2, NdL);
@@ -2091,7 +2099,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
                 }
                 want_eval = false;
             }
-            const long long tq1 = P.prof ? (long long)__builtin_readcyclecounter() : 0;
+            const long long tq1 = STM_PROF(P) ? (long long)__builtin_readcyclecounter() : 0;
             const bool was_upd = st == S_ACCEPT2;
             const int st_in = st;
             switch (st) {
@@ -2306,7 +2314,7 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             case S_W1_ITER: {  // DCSRCH._iterate with (stp, f, g) = (alpha, fval, dval)
 #ifdef STM_SM_PROF   // a build for tools/solver_prof.py: where one DCSRCH step's cycles go (profile slots 40..43: tests / dcstep / interval + clip / cuts)
                 long long smc = (long long)__builtin_readcyclecounter();
-#define STM_SM_LAP(q) if (P.prof) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) P.prof[doc * PROF_SLOTS + 40 + (q)] += now_ - smc; smc = now_; }
+#define STM_SM_LAP(q) if (STM_PROF(P)) { const long long now_ = (long long)__builtin_readcyclecounter(); if (lane == 0) STM_PROF(P)[doc * PROF_SLOTS + 40 + (q)] += now_ - smc; smc = now_; }
 #else
 #define STM_SM_LAP(q)
 #endif
@@ -2603,11 +2611,11 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             } break;
             default: st = S_FINISH; break;
             }
-            if (P.prof) {
+            if (STM_PROF(P)) {
                 const long long tq2 = (long long)__builtin_readcyclecounter();
                 t_eval += tq1 - tq0;
                 if (was_upd) t_upd += tq2 - tq1; else t_sm += tq2 - tq1;
-                if (lane == 0) P.prof[doc * PROF_SLOTS + 8 + st_in] += (tq2 - tq1) + (1LL << 40);   // cycles in the low 40 bits, visits above (slots 24.. are the post kernels')
+                if (lane == 0) STM_PROF(P)[doc * PROF_SLOTS + 8 + st_in] += (tq2 - tq1) + (1LL << 40);   // cycles in the low 40 bits, visits above (slots 24.. are the post kernels')
             }
         }
         if (NW == 2) {  // release the evaluation server
@@ -2629,11 +2637,11 @@ __global__ __launch_bounds__(64 * NW, (VPL > 2 ? 1 : VPL == 2 ? 2 : KREG > 50 ? 
             if (i < n) P.eta[doc * n + i] = x[r];
         }
         // uniform stores (every lane writes the same word)
-        if (P.prof && lane == 0) {
-            P.prof[doc * PROF_SLOTS + 0] = t_init; P.prof[doc * PROF_SLOTS + 1] = t_eval; P.prof[doc * PROF_SLOTS + 2] = t_sm; P.prof[doc * PROF_SLOTS + 3] = t_upd;
+        if (STM_PROF(P) && lane == 0) {
+            STM_PROF(P)[doc * PROF_SLOTS + 0] = t_init; STM_PROF(P)[doc * PROF_SLOTS + 1] = t_eval; STM_PROF(P)[doc * PROF_SLOTS + 2] = t_sm; STM_PROF(P)[doc * PROF_SLOTS + 3] = t_upd;
             // absolute begin / end of the document on the shader clock and the 100 MHz wall clock at its end (tools/slot_gaps.py: how many
             // documents the chip really has in flight -- what the dispatch of one workgroup per document costs; [39] the wall clock at its begin)
-            P.prof[doc * PROF_SLOTS + 45] = t_begin; P.prof[doc * PROF_SLOTS + 46] = (long long)__builtin_readcyclecounter(); P.prof[doc * PROF_SLOTS + 47] = (long long)wall_clock64();
+            STM_PROF(P)[doc * PROF_SLOTS + 45] = t_begin; STM_PROF(P)[doc * PROF_SLOTS + 46] = (long long)__builtin_readcyclecounter(); STM_PROF(P)[doc * PROF_SLOTS + 47] = (long long)wall_clock64();
         }
         if (P.status) P.status[doc] = status;
         if (P.nit) P.nit[doc] = k;
