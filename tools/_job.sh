@@ -1,3 +1,3 @@
 export TMPDIR=/tmp
-python tools/host_gaps.py 12500 30 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl"
-python tools/host_gaps.py 100000 20 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl"
+bash tools/profile_r06.sh r06 > gpurun_out/r06_profile.log 2>&1
+tail -5 gpurun_out/r06_profile.log
