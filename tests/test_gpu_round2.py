@@ -646,6 +646,26 @@ def test_bench_launches_its_own_ranks_and_strong_scaling_shards_one_corpus():
     assert np.allclose(rc["elbo_trace"], one["elbo_trace"], rtol=1e-12)
 
 
+def test_bench_under_torch_distributed_run_like_the_driver():
+    """The driver's own launch of the multi-GPU bench: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- ranks from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, no STM_RDZV_PORT: the product's TCP group
+    finds its peers through the rendezvous file keyed by MASTER_ADDR / MASTER_PORT.  Two ranks on the one GPU of this box (host reduction:
+    RCCL refuses duplicate devices); ONE JSON line, from rank 0, with the whole job's documents."""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--docs", "3000", "--vocab", "2000", "--topics", "20", "--cpu-sample", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "STM_RDZV_PORT", "STM_RDZV_SECRET")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["docs_total"] == 6000 and d["steps"] == 2
+    assert d["value"] == pytest.approx(6000 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)       # whole-job throughput
+    assert len(d["elbo_trace"]) == 2 and np.all(np.isfinite(d["elbo_trace"]))
+    assert d["strong_scaling"]["docs_total"] == 3000
+
+
 def test_explicit_rccl_on_duplicate_devices_fails_cleanly():
     """`--allreduce rccl` asked for by name must not fall back silently: two ranks on this box's single GPU make RCCL refuse
     (duplicate device) -- or, if it cannot even be loaded, say so -- and the launcher exits non-zero with the reason,
