@@ -666,6 +666,35 @@ def test_bench_under_torch_distributed_run_like_the_driver():
     assert d["strong_scaling"]["docs_total"] == 3000
 
 
+def test_bench_line_exchange_and_counter_provenance():
+    """`bench.py --gpus 1 --allreduce rccl --exchange single|split`: the line says which exchange ran (one all-reduce of the packed buffer per
+    EM iteration, or two) through a real one-rank communicator, with the same ELBO trace; `roofline.traffic` / `.compute` are measured by the
+    run itself (rocprofv3 --pmc child passes) unless switched off, and the line says which it was."""
+    def run(*extra):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "4000", "--vocab", "3000", "--topics", "50", "--steps", "2", "--warmup", "1",
+               "--cpu-sample", "0", "--late-sample", "0", *extra]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "STM_RDZV_PORT")}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    split = run("--gpus", "1", "--allreduce", "rccl", "--live-traffic", "off")
+    single = run("--gpus", "1", "--allreduce", "rccl", "--exchange", "single", "--live-traffic", "off")
+    assert split["config"]["allreduce"] == "rccl" and split["config"]["rccl_comm_count"] == [1]
+    assert split["config"]["exchange"] == "split" and split["config"]["allreduces_per_iteration"] == 2
+    assert single["config"]["exchange"] == "single" and single["config"]["allreduces_per_iteration"] == 1
+    assert single["elbo_trace"] == split["elbo_trace"]
+    assert split["roofline"]["traffic_source"] is None or split["roofline"]["traffic_source"].startswith("profiles/")   # (no committed entry for this workload)
+    import shutil
+    live = run("--gpus", "1")
+    r = live["roofline"]
+    assert r["dominant_single_kernel"]["kernel"] in ("stm::solver_kernel", "stm::post_kernel") and 0 < r["dominant_single_kernel"]["frac"] < 1
+    if shutil.which("rocprofv3"):
+        assert r["traffic_source"].startswith("live:") and r["compute_source"].startswith("live:")
+        assert r["traffic"] > 0 and all(k["traffic"] > 0 and k["compute"]["fp64_pipe_busy"] > 0 for k in r["kernels"].values())
+
+
 def test_explicit_rccl_on_duplicate_devices_fails_cleanly():
     """`--allreduce rccl` asked for by name must not fall back silently: two ranks on this box's single GPU make RCCL refuse
     (duplicate device) -- or, if it cannot even be loaded, say so -- and the launcher exits non-zero with the reason,
