@@ -84,8 +84,11 @@ __device__ __forceinline__ void by_wave(int wv, F &&f) {   // f(integral_constan
     else { if (wv == W0) f(std::integral_constant<int, W0>{}); else by_wave<W0 + 1, NWV>(wv, f); }
 }
 
+#ifndef STM_PB2_W2_OCC
+#define STM_PB2_W2_OCC 2   // waves per SIMD the two-wave form is compiled for (1: 512 registers, no spills -- a diagnostic: the LDS keeps four documents per CU)
+#endif
 template <int NB, int PC, bool DBG, int NWV = 2>
-__global__ __launch_bounds__(64 * NWV, NWV == 2 ? 2 : STM_PB2_W4_OCC) void post_big2_kernel(PostParams P) {
+__global__ __launch_bounds__(64 * NWV, NWV == 2 ? STM_PB2_W2_OCC : STM_PB2_W4_OCC) void post_big2_kernel(PostParams P) {
     static_assert(NWV == 2 || NWV == 4, "two or four waves per document");
     constexpr int NT = NB * (NB + 1) / 2, NTW = (NT + NWV - 1) / NWV;   // accumulator tiles: all / per wave (tile t belongs to wave t % NWV)
     constexpr int PITCH = 2 * PC, QP = PC / 8;
